@@ -1,0 +1,323 @@
+"""Oracle (CPU, pure torch) restatement of the reference's dense heads.
+
+TEST INFRASTRUCTURE ONLY.  Reference files followed (relative to
+/root/reference/src/sihl):
+  heads/object_detection.py:14-217,252-284   ObjectDetection (+ bbox_matching)
+  heads/semantic_segmentation.py:11-92       SemanticSegmentation
+  heads/semantic_segmentation.py:123-182     SPPM, UAFM
+  heads/multiclass_classification.py:47-52   MulticlassClassification (config-1 plumbing)
+torchvision 0.21 ``ops.complete_box_iou`` / ``complete_box_iou_loss`` are NOT in
+the container; they are restated from the published CIoU definition (SURVEY.md
+App. B) and are "parity unpinned".
+"""
+import math
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from oracle.layers import (ConvNormAct, Conv2dNormActivation, Interpolate, MLP,
+                           SequentialConvBlocks, SimpleUpscaler)
+
+
+# --------------------------------------------------------------------------- CIoU
+def _pairwise_iou_parts(b1: Tensor, b2: Tensor):
+    area1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    area2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    lt = torch.max(b1[:, None, :2], b2[None, :, :2])
+    rb = torch.min(b1[:, None, 2:], b2[None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    union = area1[:, None] + area2[None, :] - inter
+    return inter / union, union
+
+
+def complete_box_iou(boxes1: Tensor, boxes2: Tensor, eps: float = 1e-7) -> Tensor:
+    """(N,4) x (M,4) xyxy -> (N,M) CIoU = IoU - rho^2/c^2 - alpha*v."""
+    iou, _ = _pairwise_iou_parts(boxes1, boxes2)
+    lti = torch.min(boxes1[:, None, :2], boxes2[None, :, :2])
+    rbi = torch.max(boxes1[:, None, 2:], boxes2[None, :, 2:])
+    whi = (rbi - lti).clamp(min=0)
+    diag2 = whi[..., 0] ** 2 + whi[..., 1] ** 2 + eps
+    cx1 = (boxes1[:, 0] + boxes1[:, 2]) / 2
+    cy1 = (boxes1[:, 1] + boxes1[:, 3]) / 2
+    cx2 = (boxes2[:, 0] + boxes2[:, 2]) / 2
+    cy2 = (boxes2[:, 1] + boxes2[:, 3]) / 2
+    dist2 = (cx1[:, None] - cx2[None, :]) ** 2 + (cy1[:, None] - cy2[None, :]) ** 2
+    diou = iou - dist2 / diag2
+    w1 = boxes1[:, None, 2] - boxes1[:, None, 0]
+    h1 = boxes1[:, None, 3] - boxes1[:, None, 1]
+    w2 = boxes2[None, :, 2] - boxes2[None, :, 0]
+    h2 = boxes2[None, :, 3] - boxes2[None, :, 1]
+    v = (4 / math.pi ** 2) * (torch.atan(w1 / h1) - torch.atan(w2 / h2)) ** 2
+    with torch.no_grad():
+        alpha = v / (1 - iou + v + eps)
+    return diou - alpha * v
+
+
+def complete_box_iou_loss(b1: Tensor, b2: Tensor, eps: float = 1e-7) -> Tensor:
+    """Elementwise (N,4),(N,4) -> (N,) loss = 1 - IoU + rho^2/c^2 + alpha*v (reduction none)."""
+    x1, y1, x2, y2 = b1.unbind(-1)
+    x1g, y1g, x2g, y2g = b2.unbind(-1)
+    xk1, yk1 = torch.max(x1, x1g), torch.max(y1, y1g)
+    xk2, yk2 = torch.min(x2, x2g), torch.min(y2, y2g)
+    inter = torch.zeros_like(x1)
+    m = (yk2 > yk1) & (xk2 > xk1)
+    inter[m] = (xk2[m] - xk1[m]) * (yk2[m] - yk1[m])
+    union = (x2 - x1) * (y2 - y1) + (x2g - x1g) * (y2g - y1g) - inter
+    iou = inter / (union + eps)
+    xc1, yc1 = torch.min(x1, x1g), torch.min(y1, y1g)
+    xc2, yc2 = torch.max(x2, x2g), torch.max(y2, y2g)
+    diag2 = (xc2 - xc1) ** 2 + (yc2 - yc1) ** 2 + eps
+    dist2 = (((x1 + x2) - (x1g + x2g)) / 2) ** 2 + (((y1 + y2) - (y1g + y2g)) / 2) ** 2
+    diou_loss = 1 - iou + dist2 / diag2
+    v = (4 / math.pi ** 2) * (torch.atan((x2g - x1g) / (y2g - y1g)) - torch.atan((x2 - x1) / (y2 - y1))) ** 2
+    with torch.no_grad():
+        alpha = v / (1 - iou + v + eps)
+    return diou_loss + alpha * v
+
+
+# --------------------------------------------------------------------------- OD head
+def anchor_offsets_and_scales(sizes: List[Tuple[int, int]], device=None) -> Tuple[Tensor, Tensor]:
+    """Cell centres (cx,cy,cx,cy) and half-cell (-1/2w,-1/2h,1/2w,1/2h) per level, concatenated
+    (object_detection.py:83-97).  ``sizes`` = [(h, w)] for bottom..top level."""
+    offs, scls = [], []
+    for h, w in sizes:
+        y0, x0 = 1 / h / 2, 1 / w / 2
+        ys = torch.linspace(y0, 1 - y0, steps=h, device=device)
+        xs = torch.linspace(x0, 1 - x0, steps=w, device=device)
+        gx = xs[None, :].expand(h, w).reshape(-1)
+        gy = ys[:, None].expand(h, w).reshape(-1)
+        offs.append(torch.stack([gx, gy, gx, gy], dim=1))
+        scls.append(torch.tensor([-x0, -y0, x0, y0], device=device).expand(h * w, 4))
+    return torch.cat(offs), torch.cat(scls)
+
+
+def bbox_matching(anchors: Tensor, gt_boxes: Tensor, topk: int, relative: bool = False):
+    """Top-k-per-GT one-to-many assignment (object_detection.py:252-284)."""
+    A, G = anchors.shape[0], gt_boxes.shape[0]
+    assign = torch.full((A,), -1, device=anchors.device)
+    o2m = torch.zeros((A,), device=anchors.device)
+    if G == 0:
+        return assign, o2m
+    ious = complete_box_iou(anchors, gt_boxes).clamp(0)
+    top_v, top_i = torch.topk(ious, k=topk, dim=0)
+    in_topk = torch.zeros((A, G), dtype=torch.bool, device=anchors.device)
+    in_topk.scatter_(0, top_i, True)
+    best_iou, best_gt = torch.max(ious * in_topk.float(), dim=1)
+    valid = in_topk.any(dim=1)
+    assign[valid] = best_gt[valid]
+    if not relative:
+        o2m[valid] = best_iou[valid]
+        return assign, o2m
+    denom = top_v[0][best_gt]
+    o2m[valid] = (best_iou[valid] / denom[valid]).nan_to_num(0)
+    return assign, o2m
+
+
+class ObjectDetection(nn.Module):
+    """Anchor-free detector: per-level 1x1 conv+BN laterals, four shared MLPs, top-k decode."""
+
+    def __init__(self, in_channels: List[int], num_classes: int, bottom_level: int = 3,
+                 top_level: int = 5, num_channels: int = 256, num_layers: int = 4,
+                 max_instances: int = 100):
+        assert num_classes > 0 and len(in_channels) > top_level
+        assert 0 < bottom_level <= top_level and num_channels % 4 == 0
+        assert num_layers >= 0 and max_instances > 0
+        super().__init__()
+        self.in_channels, self.num_classes = in_channels, num_classes
+        self.bottom_level, self.top_level = bottom_level, top_level
+        self.levels = range(bottom_level, top_level + 1)
+        self.num_channels, self.num_layers = num_channels, num_layers
+        self.max_instances, self.topk = max_instances, 9
+        self.laterals = nn.ModuleList([
+            Conv2dNormActivation(in_channels[l], num_channels, 1, activation_layer=None)
+            for l in self.levels])
+        hidden = [num_channels] * num_layers
+
+        def mlp(out):
+            return MLP(num_channels, hidden + [out], norm_layer=nn.LayerNorm, activation_layer=nn.SiLU)
+
+        self.loc_head = mlp(1)
+        self.loc_head[-2].bias.data.fill_(-5.0)  # object_detection.py:58
+        self.cls_head = mlp(num_classes)
+        self.box_head = mlp(4)
+        self.iou_head = mlp(1)
+        self.output_shapes = {
+            "num_instances": ("batch_size",),
+            "scores": ("batch_size", max_instances),
+            "classes": ("batch_size", max_instances),
+            "boxes": ("batch_size", max_instances, 4),
+        }
+
+    bbox_matching = staticmethod(bbox_matching)
+
+    def _flat_feats(self, inputs: List[Tensor]) -> Tensor:
+        feats = [lat(inputs[l]) for l, lat in zip(self.levels, self.laterals)]
+        return torch.cat([f.flatten(2).transpose(1, 2) for f in feats], dim=1)  # (B, P, C)
+
+    def get_offsets_and_scales(self, inputs: List[Tensor]) -> Tuple[Tensor, Tensor]:
+        return anchor_offsets_and_scales([tuple(inputs[l].shape[2:]) for l in self.levels],
+                                         device=inputs[0].device)
+
+    def forward(self, inputs: List[Tensor]):
+        B, _, H, W = inputs[0].shape
+        full = torch.tensor([[[W, H, W, H]]], device=inputs[0].device)
+        flat = self._flat_feats(inputs)
+        offsets, scales = self.get_offsets_and_scales(inputs)
+        loc_logits, idx = self.loc_head(flat).squeeze(2).topk(self.max_instances, dim=1)
+        rows = torch.arange(B)[:, None].expand(B, self.max_instances)
+        sel = flat[rows, idx]
+        scores = loc_logits.sigmoid()
+        num_instances = (scores > 0.5).sum(dim=1)
+        classes = self.cls_head(sel).max(dim=2).indices
+        boxes = (offsets[idx] + scales[idx] * self.box_head(sel).exp()) * full
+        return num_instances, scores, classes, boxes
+
+    def training_step(self, inputs: List[Tensor], classes: List[Tensor], boxes: List[Tensor],
+                      is_validating: bool = False):
+        assert len(inputs) > self.top_level
+        B, _, H, W = inputs[0].shape
+        full = torch.tensor([[W, H, W, H]], device=inputs[0].device)
+        offsets, scales = self.get_offsets_and_scales(inputs)
+        anchors = (offsets + scales) * full
+        matches = [bbox_matching(anchors, boxes[b], self.topk, relative=True) for b in range(B)]
+        assignment = torch.stack([m[0] for m in matches])
+        rel_iou = torch.stack([m[1] for m in matches])
+        flat = self._flat_feats(inputs)
+
+        loc_logits = self.loc_head(flat).squeeze(2)
+        loc_target = (rel_iou == 1.0).to(torch.float32)
+        loc_loss = F.binary_cross_entropy_with_logits(loc_logits.float(), loc_target, reduction="none")
+        loc_loss = loc_loss.sum() / loc_target.sum()
+        if rel_iou.max() == 0:  # object_detection.py:165-172
+            z = torch.zeros_like(loc_loss)
+            return loc_loss, {"location_loss": loc_loss, "box_loss": z, "class_loss": z, "iou_loss": z}
+
+        iou_preds = self.iou_head(flat).squeeze(2)
+        iou_loss = F.mse_loss(iou_preds.float(), rel_iou, reduction="none").sum() / rel_iou.sum()
+
+        mask = rel_iou > 0
+        wts = rel_iou[mask]
+        sel = flat[mask]
+        off_sel = torch.cat([offsets[m] for m in mask])
+        scl_sel = torch.cat([scales[m] for m in mask])
+        box_preds = off_sel + scl_sel * self.box_head(sel).exp()
+        box_target = torch.cat([boxes[b][assignment[b, m]] for b, m in enumerate(mask)])
+        box_loss = complete_box_iou_loss(box_preds.float(), box_target.to(torch.float32) / full)
+        box_loss = (wts * box_loss).sum() / wts.sum()
+
+        cls_logits = self.cls_head(sel)
+        cls_target = torch.cat([classes[b][assignment[b, m]] for b, m in enumerate(mask)])
+        cls_loss = F.cross_entropy(cls_logits.float(), cls_target, reduction="none")
+        cls_loss = (wts * cls_loss).sum() / wts.sum()
+
+        loss = loc_loss + 10 * box_loss + cls_loss + iou_loss
+        return loss, {"location_loss": loc_loss, "box_loss": box_loss,
+                      "class_loss": cls_loss, "iou_loss": iou_loss}
+
+
+# --------------------------------------------------------------------------- SemSeg head
+class SPPM(nn.Module):
+    """Bilinear "pooling" pyramid: resize to p x p, 1x1 ConvNormAct, resize back, sum, 1x1
+    (semantic_segmentation.py:123-160)."""
+
+    def __init__(self, in_channels, out_channels, pool_sizes=(1, 2, 4), with_shortcut=False):
+        super().__init__()
+        self.with_shortcut = with_shortcut
+        self.pools = nn.ModuleList(
+            [nn.Sequential(Interpolate(size=p), ConvNormAct(in_channels, out_channels, 1))
+             for p in pool_sizes] if len(pool_sizes) > 0 else [nn.Identity()])
+        if with_shortcut:
+            self.shortcut = ConvNormAct(in_channels, out_channels, 1)
+        self.out_conv = ConvNormAct(out_channels, out_channels, 1)
+
+    def forward(self, x: Tensor) -> Tensor:
+        size = x.shape[2:]
+        acc = None
+        for pool in self.pools:
+            y = F.interpolate(pool(x), size=size, mode="bilinear")
+            acc = y if acc is None else acc + y
+        if self.with_shortcut:
+            acc = acc + self.shortcut(x)
+        return self.out_conv(acc)
+
+
+class UAFM(nn.Module):
+    """alpha = sigmoid(conv3x3([mean_c x1, max_c x1, mean_c x2, max_c x2])); x1*alpha + x2*(1-alpha)
+    (semantic_segmentation.py:163-182)."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.conv = ConvNormAct(4, 1, norm=None, act="sigmoid")
+
+    def forward(self, x1: Tensor, x2: Tensor) -> Tensor:
+        stats = torch.cat([x1.mean(1, keepdim=True), x1.amax(1, keepdim=True),
+                           x2.mean(1, keepdim=True), x2.amax(1, keepdim=True)], dim=1)
+        a = self.conv(stats)
+        return x1 * a + x2 * (1 - a)
+
+
+class SemanticSegmentation(nn.Module):
+    """PP-LiteSeg style decoder (semantic_segmentation.py:11-92)."""
+
+    def __init__(self, in_channels: List[int], num_classes: int, bottom_level: int = 3,
+                 top_level: int = 5, num_channels: int = 256, num_layers: int = 3,
+                 pool_sizes=(1, 2, 4), ignore_index=None):
+        assert num_classes > 0 and len(in_channels) > top_level >= bottom_level > 0
+        assert num_channels > 0 and num_layers >= 0
+        super().__init__()
+        self.in_channels, self.num_classes = in_channels, num_classes
+        self.num_channels, self.num_layers = num_channels, num_layers
+        self.pool_sizes = tuple(pool_sizes)
+        self.bottom_level, self.top_level = bottom_level, top_level
+        self.ignore_index = ignore_index or -100  # semantic_segmentation.py:51 (0 is un-ignorable)
+        self.levels = list(range(bottom_level, top_level + 1))
+        self.rev_levels = list(reversed(range(bottom_level, top_level)))
+        self.context_aggregation = SPPM(in_channels[top_level], num_channels, self.pool_sizes)
+        self.lateral_convs = nn.ModuleList([ConvNormAct(in_channels[l], num_channels) for l in self.rev_levels])
+        self.upscalers = nn.ModuleList([SimpleUpscaler(num_channels, num_channels) for _ in self.rev_levels])
+        self.fusions = nn.ModuleList([UAFM(num_channels, num_channels) for _ in self.rev_levels])
+        self.out_conv = nn.Sequential(SequentialConvBlocks(num_channels, num_channels, num_layers),
+                                      nn.Conv2d(num_channels, num_classes, kernel_size=1))
+        self.output_shapes = {"score_maps": ("batch_size", "height", "width"),
+                              "class_maps": ("batch_size", "height", "width")}
+
+    def get_logits(self, inputs: List[Tensor]) -> Tensor:
+        x = self.context_aggregation(inputs[self.top_level])
+        for l, lat, up, fuse in zip(self.rev_levels, self.lateral_convs, self.upscalers, self.fusions):
+            x = fuse(lat(inputs[l]), up(x))
+        return self.out_conv(x)
+
+    def forward(self, inputs: List[Tensor]):
+        x = F.interpolate(self.get_logits(inputs), size=inputs[0].shape[2:])  # nearest
+        return x.softmax(dim=1).max(dim=1)
+
+    def training_step(self, inputs: List[Tensor], targets: Tensor):
+        logits = F.interpolate(self.get_logits(inputs), size=targets.shape[1:])
+        return F.cross_entropy(logits, targets, ignore_index=self.ignore_index), {}
+
+
+# --------------------------------------------------------------------------- config-1 plumbing head
+class MulticlassClassification(nn.Module):
+    """conv blocks on one level -> 1x1 -> global average -> logits
+    (multiclass_classification.py:11-69); stock PyTorch only (BASELINE config 1)."""
+
+    def __init__(self, in_channels: List[int], num_classes: int, num_channels: int = 256,
+                 num_layers: int = 1, level: int = 5, label_smoothing: float = 0.0):
+        assert num_classes > 0 and len(in_channels) > level and num_channels > 0 and num_layers > 0
+        super().__init__()
+        self.level, self.num_classes, self.label_smoothing = level, num_classes, label_smoothing
+        self.convs = nn.Sequential(
+            SequentialConvBlocks(in_channels[level], num_channels, num_layers),
+            nn.Conv2d(num_channels, num_classes, kernel_size=1),
+            nn.AdaptiveAvgPool2d(1), nn.Flatten())
+        self.output_shapes = {"scores": ("batch_size", num_classes), "classes": ("batch_size",)}
+
+    def forward(self, inputs: List[Tensor]):
+        return self.convs(inputs[self.level]).softmax(dim=1).max(dim=1)
+
+    def training_step(self, inputs: List[Tensor], target: Tensor):
+        logits = self.convs(inputs[self.level])
+        return F.cross_entropy(logits, target.to(logits.device), label_smoothing=self.label_smoothing), {}

@@ -1,0 +1,51 @@
+"""Helpers to replay a golden case (tests/golden/cases.py) on some namespace of classes."""
+import os
+import re
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_npz(name):
+    return dict(np.load(os.path.join(HERE, f"{name}.npz"), allow_pickle=False))
+
+
+def _unflatten(prefix, data):
+    if f"{prefix}.len" in data:
+        return [_unflatten(f"{prefix}.{i}", data) for i in range(int(data[f"{prefix}.len"]))]
+    return torch.from_numpy(data[prefix].copy())
+
+
+def golden_inputs(data):
+    keys = {re.match(r"in\.([^.]+)", k).group(1) for k in data if k.startswith("in.")}
+    return {k: _unflatten(f"in.{k}", data) for k in keys}
+
+
+def golden_state_dict(data, prefix="sd."):
+    return {k[len(prefix):]: torch.from_numpy(v.copy()) for k, v in data.items() if k.startswith(prefix)}
+
+
+def golden_results(data):
+    return {k[4:]: torch.from_numpy(v.copy()) for k, v in data.items() if k.startswith("res.")}
+
+
+def replay(case, ns, data, device="cpu", dtype=torch.float32, prepare=None):
+    """Build the case's module from ``ns``, load the golden state_dict, run on ``device``."""
+    torch.manual_seed(1234)
+    m = case.build(ns)
+    missing = m.load_state_dict(golden_state_dict(data), strict=True)
+    m.train(case.train)
+    m = m.to(device)
+    if prepare is not None:
+        m = prepare(m)
+
+    def mv(x):
+        if isinstance(x, list):
+            return [mv(t) for t in x]
+        return x.to(device=device, dtype=dtype) if x.is_floating_point() else x.to(device)
+
+    inp = {k: mv(v) for k, v in golden_inputs(data).items()}
+    res = case.run(m, inp)
+    return m, {k: v.detach().float().cpu() if v.is_floating_point() else v.detach().cpu() for k, v in res.items()}
