@@ -1,0 +1,142 @@
+"""Level-list ResNet backbone on PyTorch-ROCm (reference src/sihl/torchvision_backbone.py:42-49,102-210).
+
+The backbone is not a hand-kernel target of this round: it is a plain ``torch.nn``
+ResNet (torchvision's published architecture; torchvision itself is absent here) running
+channels_last on PyTorch-ROCm, honouring the reference's level contract: level 0 is the input,
+level 1 = ``relu`` BEFORE max-pool, levels 2..5 = ``layer1..layer4``, levels above 5 come from
+AntialiasedDownscaler blocks (HIP path).  Parameter names follow torchvision's under ``model.``.
+"""
+from typing import List
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from sihl_amd.layers.scalers import AntialiasedDownscaler
+
+
+class _Basic(nn.Module):
+    expansion = 1
+
+    def __init__(self, cin, width, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, width, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(width, width, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.downsample = None
+        if stride != 1 or cin != width:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, width, 1, stride, bias=False), nn.BatchNorm2d(width))
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        return self.relu(self.bn2(self.conv2(y)) + idt)
+
+
+class _Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, cin, width, stride):
+        super().__init__()
+        cout = width * 4
+        self.conv1 = nn.Conv2d(cin, width, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, cout, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        return self.relu(self.bn3(self.conv3(y)) + idt)
+
+
+RESNETS = {"resnet18": (_Basic, [2, 2, 2, 2]), "resnet34": (_Basic, [3, 4, 6, 3]),
+           "resnet50": (_Bottleneck, [3, 4, 6, 3]), "resnet101": (_Bottleneck, [3, 4, 23, 3]),
+           "resnet152": (_Bottleneck, [3, 8, 36, 3])}
+
+
+class _Trunk(nn.Module):
+    def __init__(self, name: str, input_channels: int):
+        super().__init__()
+        block, depths = RESNETS[name]
+        self.conv1 = nn.Conv2d(input_channels, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        cin = 64
+        for i, (w, n) in enumerate(zip([64, 128, 256, 512], depths)):
+            blocks = []
+            for j in range(n):
+                blocks.append(block(cin, w, (2 if i > 0 else 1) if j == 0 else 1))
+                cin = w * block.expansion
+            setattr(self, f"layer{i + 1}", nn.Sequential(*blocks))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, x: Tensor, n_taps: int) -> List[Tensor]:
+        taps = [self.relu(self.bn1(self.conv1(x)))]
+        y = self.maxpool(taps[0])
+        for i in range(1, 5):
+            if len(taps) >= n_taps:
+                break
+            y = getattr(self, f"layer{i}")(y)
+            taps.append(y)
+        return taps[:n_taps]
+
+
+class ResNetBackbone(nn.Module):
+    def __init__(self, name: str = "resnet50", pretrained: bool = False, input_channels: int = 3,
+                 top_level: int = 5, frozen_levels: int = 0):
+        super().__init__()
+        if name not in RESNETS:
+            raise ValueError(f"Architecture {name} is not supported. Select from {tuple(RESNETS)}")
+        if pretrained:
+            raise RuntimeError("pretrained weights need network access, which this environment does not have")
+        self.name, self.top_level = name, top_level
+        self.model = _Trunk(name, input_channels)
+        self.n_taps = min(top_level, 5)
+        min_size = 2 ** (top_level + 1)
+        self.dummy_input = torch.zeros(1, input_channels, min_size, min_size)
+        with torch.no_grad():
+            was = self.model.training
+            self.model.eval()
+            self.out_channels = [input_channels] + [t.shape[1] for t in self.model(self.dummy_input, self.n_taps)]
+            self.model.train(was)
+        c = self.out_channels[-1]
+        extra = range(top_level - 5)
+        self.out_channels += [c for _ in extra]
+        self.downscalers = nn.ModuleList([AntialiasedDownscaler(c, c) for _ in extra])
+        self.freeze_levels(frozen_levels)
+
+    def freeze_levels(self, num_levels: int) -> None:
+        """Freeze the modules feeding the first ``num_levels`` levels (reference :189-210); <0 freezes all."""
+        names = ["conv1", "bn1", "layer1", "layer2", "layer3", "layer4"]
+        upto = {0: 0, 1: 2}.get(num_levels, min(num_levels + 1, len(names))) if num_levels >= 0 else len(names)
+        for i, n in enumerate(names):
+            for p in getattr(self.model, n).parameters():
+                p.requires_grad_(i >= upto)
+
+    def forward(self, input: Tensor) -> List[Tensor]:
+        assert input.shape[2] % 2 ** self.top_level == 0
+        assert input.shape[3] % 2 ** self.top_level == 0
+        H, W = input.shape[2:]
+        outs = [input]
+        for lvl, t in enumerate(self.model(input, self.n_taps), start=1):
+            size = (H // 2 ** lvl, W // 2 ** lvl)
+            outs.append(t if tuple(t.shape[2:]) == size else F.interpolate(t, size=size))
+        for ds in self.downscalers:
+            outs.append(ds(outs[-1]))
+        return outs
+
+
+TorchvisionBackbone = ResNetBackbone  # same constructor keywords as the reference class for resnets

@@ -1,0 +1,1021 @@
+// HBM-bound NHWC elementwise / reduction kernels of the sihl hot path (gfx950).
+// Every kernel moves 16-byte channel vectors (8 bf16 / 4 fp32 per lane), computes in fp32 and is
+// written so that each logical tensor is read once and written once:
+//   * BatchNorm batch-statistics finalize + per-channel affine/activation   (convblocks.py:82-85, fpn.py:26-37)
+//   * FastNormalizedFusion fused with its producer: bilinear x2 upsample + 2-way weighted sum, and
+//     reflect-pad binomial blur (stride 2) + 3-way weighted sum               (bifpn.py:10-17,39-53; scalers.py:36-47;
+//                                                                              pooling.py:7-26)
+//   * their adjoints (input grads + fusion-weight grads as block reductions)
+//   * LayerNorm + SiLU of the MLP hidden layers and its backward             (heads/object_detection.py:51-61)
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+template <typename T> __device__ __forceinline__ void ldv(const T* p, float (&f)[16 / sizeof(T)]) {
+  unpack16(*(const uint4*)p, f, T());
+}
+template <typename T> __device__ __forceinline__ void stv(T* p, const float (&f)[16 / sizeof(T)]) {
+  *(uint4*)p = pack16(f, T());
+}
+
+__device__ __forceinline__ void softmax_w(const float* raw, int n, float (&w)[3]) {
+  w[0] = w[1] = w[2] = 0.f;
+  if (!raw) { w[0] = 1.f; return; }
+  float m = raw[0];
+  for (int i = 1; i < n; ++i) m = fmaxf(m, raw[i]);
+  float s = 0.f;
+  for (int i = 0; i < n; ++i) { w[i] = expf(raw[i] - m); s += w[i]; }
+  for (int i = 0; i < n; ++i) w[i] /= s;
+}
+
+// block-wide sum of up to 3 values -> atomicAdd into acc[0..n)
+__device__ __forceinline__ void block_accumulate(float (&v)[3], int n, float* acc) {
+  __shared__ float red[3][TPB / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = 0; i < n; ++i) {
+    const float s = wave_sum(v[i]);
+    if (lane == 0) red[i][wave] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < n) {
+    float s = 0.f;
+    for (int w = 0; w < TPB / 64; ++w) s += red[threadIdx.x][w];
+    atomicAdd(acc + threadIdx.x, s);
+  }
+}
+
+// ------------------------------------------------------------------ BN finalize
+// partials [R][2][C] -> mean, rstd, scale = gamma*rstd, shift = beta - mean*scale; running stats updated.
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int R, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* running_mean, float* running_var, float* mean_out,
+                                   float* rstd_out, float* scale, float* shift) {
+  __shared__ double sh[2][4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  double s = 0.0, q = 0.0;
+  if (c < C)
+    for (int r = ry; r < R; r += 4) {
+      s += (double)part[((long)r * 2 + 0) * C + c];
+      q += (double)part[((long)r * 2 + 1) * C + c];
+    }
+  sh[0][ry][cx] = s;
+  sh[1][ry][cx] = q;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    s = sh[0][0][cx] + sh[0][1][cx] + sh[0][2][cx] + sh[0][3][cx];
+    q = sh[1][0][cx] + sh[1][1][cx] + sh[1][2][cx] + sh[1][3][cx];
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    mean_out[c] = (float)mean;
+    rstd_out[c] = rstd;
+    scale[c] = g * rstd;
+    shift[c] = b - (float)mean * g * rstd;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) {
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  }
+}
+
+// scale/shift from running statistics (eval mode)
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, int C, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float rstd = 1.f / sqrtf(rv[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  scale[c] = g * rstd;
+  shift[c] = b - rm[c] * g * rstd;
+}
+
+// ------------------------------------------------------------------ y = act(x*scale[c] + shift[c])
+template <typename T>
+__global__ void affine_act_kernel(const T* __restrict__ x, T* __restrict__ y, long nvec, int cvec,
+                                  const float* __restrict__ scale, const float* __restrict__ shift, int act) {
+  constexpr int V = 16 / sizeof(T);
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+    const int c = (int)(i % cvec) * V;
+    float f[V];
+    ldv(x + i * V, f);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float v = f[e];
+      if (scale) v = v * scale[c + e] + (shift ? shift[c + e] : 0.f);
+      f[e] = apply_act(v, act);
+    }
+    stv(y + i * V, f);
+  }
+}
+
+// dx = dy * act'(x*scale+shift) * scale ; used for stand-alone activations (silu / sigmoid / relu)
+template <typename T>
+__global__ void affine_act_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, long nvec,
+                                      int cvec, const float* __restrict__ scale, const float* __restrict__ shift,
+                                      int act) {
+  constexpr int V = 16 / sizeof(T);
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+    const int c = (int)(i % cvec) * V;
+    float f[V], g[V];
+    ldv(x + i * V, f);
+    ldv(dy + i * V, g);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float s = scale ? scale[c + e] : 1.f;
+      const float v = f[e] * s + (shift ? shift[c + e] : 0.f);
+      g[e] = g[e] * act_grad(v, act) * s;
+    }
+    stv(dx + i * V, g);
+  }
+}
+
+// ------------------------------------------------------------------ bilinear x2 (align_corners=False) helpers
+struct Lerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lerp up2_src(int dst, int in_size) {
+  float src = 0.5f * (dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  Lerp r;
+  r.i0 = (int)src;
+  r.i1 = min(r.i0 + 1, in_size - 1);
+  r.l1 = src - r.i0;
+  r.l0 = 1.f - r.l1;
+  return r;
+}
+__device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// out = w0 * up2(a) + w1 * b          a: [N][H/2][W/2][C], b/out: [N][H][W][C]
+template <typename T>
+__global__ void fuse_up2_kernel(const T* __restrict__ a, const T* __restrict__ b, const float* __restrict__ wraw,
+                                T* __restrict__ out, int N, int H, int W, int C) {
+  constexpr int V = 16 / sizeof(T);
+  const int cvec = C / V, h2 = H / 2, w2 = W / 2;
+  const long nvec = (long)N * H * W * cvec;
+  float w[3];
+  softmax_w(wraw, 2, w);
+  if (!b) { w[0] = 1.f; w[1] = 0.f; }
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+    const int cv = (int)(i % cvec);
+    long pix = i / cvec;
+    const int x = (int)(pix % W); pix /= W;
+    const int y = (int)(pix % H);
+    const int n = (int)(pix / H);
+    const Lerp ly = up2_src(y, h2), lx = up2_src(x, w2);
+    const T* an = a + (long)n * h2 * w2 * C + cv * V;
+    float f00[V], f01[V], f10[V], f11[V], o[V];
+    ldv(an + ((long)ly.i0 * w2 + lx.i0) * C, f00);
+    ldv(an + ((long)ly.i0 * w2 + lx.i1) * C, f01);
+    ldv(an + ((long)ly.i1 * w2 + lx.i0) * C, f10);
+    ldv(an + ((long)ly.i1 * w2 + lx.i1) * C, f11);
+    if (b) ldv(b + i * V, o);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float up = ly.l0 * (lx.l0 * f00[e] + lx.l1 * f01[e]) + ly.l1 * (lx.l0 * f10[e] + lx.l1 * f11[e]);
+      o[e] = b ? w[0] * up + w[1] * o[e] : up;
+    }
+    stv(out + i * V, o);
+  }
+}
+
+// high-res pass of the adjoint: db = w1*dout, g0 += <dout, up2(a)>, g1 += <dout, b>
+template <typename T>
+__global__ void fuse_up2_bwd_hi_kernel(const T* __restrict__ dout, const T* __restrict__ a, const T* __restrict__ b,
+                                       const float* __restrict__ wraw, T* __restrict__ db, float* gacc, int N, int H,
+                                       int W, int C) {
+  constexpr int V = 16 / sizeof(T);
+  const int cvec = C / V, h2 = H / 2, w2 = W / 2;
+  const long nvec = (long)N * H * W * cvec;
+  float w[3];
+  softmax_w(wraw, 2, w);
+  float g[3] = {0.f, 0.f, 0.f};
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+    const int cv = (int)(i % cvec);
+    long pix = i / cvec;
+    const int x = (int)(pix % W); pix /= W;
+    const int y = (int)(pix % H);
+    const int n = (int)(pix / H);
+    float d[V], bb[V];
+    ldv(dout + i * V, d);
+    ldv(b + i * V, bb);
+    if (gacc) {
+      const Lerp ly = up2_src(y, h2), lx = up2_src(x, w2);
+      const T* an = a + (long)n * h2 * w2 * C + cv * V;
+      float f00[V], f01[V], f10[V], f11[V];
+      ldv(an + ((long)ly.i0 * w2 + lx.i0) * C, f00);
+      ldv(an + ((long)ly.i0 * w2 + lx.i1) * C, f01);
+      ldv(an + ((long)ly.i1 * w2 + lx.i0) * C, f10);
+      ldv(an + ((long)ly.i1 * w2 + lx.i1) * C, f11);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float up = ly.l0 * (lx.l0 * f00[e] + lx.l1 * f01[e]) + ly.l1 * (lx.l0 * f10[e] + lx.l1 * f11[e]);
+        g[0] += d[e] * up;
+        g[1] += d[e] * bb[e];
+      }
+    }
+    if (db) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) d[e] *= w[1];
+      stv(db + i * V, d);
+    }
+  }
+  if (gacc) block_accumulate(g, 2, gacc);
+}
+
+// low-res pass of the adjoint: da[i][j] = w0 * sum_{y,x} cy(y,i) cx(x,j) dout[y][x]
+template <typename T>
+__global__ void up2_adjoint_kernel(const T* __restrict__ dout, const float* __restrict__ wraw, T* __restrict__ da,
+                                   int N, int H, int W, int C) {
+  constexpr int V = 16 / sizeof(T);
+  const int cvec = C / V, h2 = H / 2, w2 = W / 2;
+  const long nvec = (long)N * h2 * w2 * cvec;
+  float w[3];
+  softmax_w(wraw, 2, w);
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+    const int cv = (int)(i % cvec);
+    long pix = i / cvec;
+    const int xj = (int)(pix % w2); pix /= w2;
+    const int yi = (int)(pix % h2);
+    const int n = (int)(pix / h2);
+    float wy[4], wx[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int y = 2 * yi - 1 + t, x = 2 * xj - 1 + t;
+      wy[t] = wx[t] = 0.f;
+      if (y >= 0 && y < H) { const Lerp l = up2_src(y, h2); wy[t] = (l.i0 == yi ? l.l0 : 0.f) + (l.i1 == yi ? l.l1 : 0.f); }
+      if (x >= 0 && x < W) { const Lerp l = up2_src(x, w2); wx[t] = (l.i0 == xj ? l.l0 : 0.f) + (l.i1 == xj ? l.l1 : 0.f); }
+    }
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+    const T* dn = dout + (long)n * H * W * C + cv * V;
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty) {
+      if (wy[ty] == 0.f) continue;
+      const int y = 2 * yi - 1 + ty;
+#pragma unroll
+      for (int tx = 0; tx < 4; ++tx) {
+        if (wx[tx] == 0.f) continue;
+        const int x = 2 * xj - 1 + tx;
+        float d[V];
+        ldv(dn + ((long)y * W + x) * C, d);
+        const float k = wy[ty] * wx[tx];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] += k * d[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] *= w[0];
+    stv(da + i * V, acc);
+  }
+}
+
+// ------------------------------------------------------------------ blur (reflect, [1,2,1]^2/16, stride 2) + fuse
+// out = w0*blur(a) + w1*b + w2*c       a: [N][H][W][C]; b,c,out: [N][Ho][Wo][C]; b==null -> out = blur(a)
+template <typename T>
+__global__ void blur_fuse_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c,
+                                 const float* __restrict__ wraw, T* __restrict__ out, int N, int H, int W, int Ho,
+                                 int Wo, int C) {
+  constexpr int V = 16 / sizeof(T);
+  const int cvec = C / V;
+  const long nvec = (long)N * Ho * Wo * cvec;
+  float w[3];
+  softmax_w(b ? wraw : nullptr, 3, w);
+  const float k1[3] = {0.25f, 0.5f, 0.25f};
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+    const int cv = (int)(i % cvec);
+    long pix = i / cvec;
+    const int ox = (int)(pix % Wo); pix /= Wo;
+    const int oy = (int)(pix % Ho);
+    const int n = (int)(pix / Ho);
+    const T* an = a + (long)n * H * W * C + cv * V;
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int y = reflect1(2 * oy + dy - 1, H);
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int x = reflect1(2 * ox + dx - 1, W);
+        float f[V];
+        ldv(an + ((long)y * W + x) * C, f);
+        const float k = k1[dy] * k1[dx];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] += k * f[e];
+      }
+    }
+    if (b) {
+      float fb[V], fc[V];
+      ldv(b + i * V, fb);
+      ldv(c + i * V, fc);
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] = w[0] * acc[e] + w[1] * fb[e] + w[2] * fc[e];
+    }
+    stv(out + i * V, acc);
+  }
+}
+
+// low-res pass of the adjoint: db = w1*dout, dc = w2*dout, g += <dout, {blur(a), b, c}>
+template <typename T>
+__global__ void blur_fuse_bwd_lo_kernel(const T* __restrict__ dout, const T* __restrict__ a, const T* __restrict__ b,
+                                        const T* __restrict__ c, const float* __restrict__ wraw, T* __restrict__ db,
+                                        T* __restrict__ dc, float* gacc, int N, int H, int W, int Ho, int Wo, int C) {
+  constexpr int V = 16 / sizeof(T);
+  const int cvec = C / V;
+  const long nvec = (long)N * Ho * Wo * cvec;
+  float w[3];
+  softmax_w(wraw, 3, w);
+  const float k1[3] = {0.25f, 0.5f, 0.25f};
+  float g[3] = {0.f, 0.f, 0.f};
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+    const int cv = (int)(i % cvec);
+    long pix = i / cvec;
+    const int ox = (int)(pix % Wo); pix /= Wo;
+    const int oy = (int)(pix % Ho);
+    const int n = (int)(pix / Ho);
+    float d[V], fb[V], fc[V];
+    ldv(dout + i * V, d);
+    ldv(b + i * V, fb);
+    ldv(c + i * V, fc);
+    if (gacc) {
+      const T* an = a + (long)n * H * W * C + cv * V;
+      float bl[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) bl[e] = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int y = reflect1(2 * oy + dy - 1, H);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int x = reflect1(2 * ox + dx - 1, W);
+          float f[V];
+          ldv(an + ((long)y * W + x) * C, f);
+          const float k = k1[dy] * k1[dx];
+#pragma unroll
+          for (int e = 0; e < V; ++e) bl[e] += k * f[e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < V; ++e) { g[0] += d[e] * bl[e]; g[1] += d[e] * fb[e]; g[2] += d[e] * fc[e]; }
+    }
+    if (db) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) fb[e] = w[1] * d[e];
+      stv(db + i * V, fb);
+    }
+    if (dc) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) fc[e] = w[2] * d[e];
+      stv(dc + i * V, fc);
+    }
+  }
+  if (gacc) block_accumulate(g, 3, gacc);
+}
+
+// high-res pass of the adjoint: da[y][x] = w0 * sum_{oy,ox} ky(y,oy) kx(x,ox) dout[oy][ox]
+template <typename T>
+__global__ void blur_adjoint_kernel(const T* __restrict__ dout, const float* __restrict__ wraw, T* __restrict__ da,
+                                    int N, int H, int W, int Ho, int Wo, int C) {
+  constexpr int V = 16 / sizeof(T);
+  const int cvec = C / V;
+  const long nvec = (long)N * H * W * cvec;
+  float w[3];
+  softmax_w(wraw, 3, w);
+  const float k1[3] = {0.25f, 0.5f, 0.25f};
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+    const int cv = (int)(i % cvec);
+    long pix = i / cvec;
+    const int x = (int)(pix % W); pix /= W;
+    const int y = (int)(pix % H);
+    const int n = (int)(pix / H);
+    // candidate output rows: those whose 3-tap window (after reflection) can touch y
+    const int oy_lo = max(0, (y - 2) / 2), ox_lo = max(0, (x - 2) / 2);
+    float wy[3], wx[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      wy[t] = wx[t] = 0.f;
+      const int oy = oy_lo + t, ox = ox_lo + t;
+      if (oy < Ho)
+        for (int d = 0; d < 3; ++d) if (reflect1(2 * oy + d - 1, H) == y) wy[t] += k1[d];
+      if (ox < Wo)
+        for (int d = 0; d < 3; ++d) if (reflect1(2 * ox + d - 1, W) == x) wx[t] += k1[d];
+    }
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+    const T* dn = dout + (long)n * Ho * Wo * C + cv * V;
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+      if (wy[ty] == 0.f) continue;
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        if (wx[tx] == 0.f) continue;
+        float d[V];
+        ldv(dn + ((long)(oy_lo + ty) * Wo + (ox_lo + tx)) * C, d);
+        const float k = wy[ty] * wx[tx];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] += k * d[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] *= w[0];
+    stv(da + i * V, acc);
+  }
+}
+
+
+// ------------------------------------------------------------------ stand-alone FastNormalizedFusion (n = 2 or 3)
+template <typename T>
+__global__ void fuse_sum_kernel(const T* __restrict__ x0, const T* __restrict__ x1, const T* __restrict__ x2,
+                                const float* __restrict__ wraw, T* __restrict__ out, long nvec, int n) {
+  constexpr int V = 16 / sizeof(T);
+  float w[3];
+  softmax_w(wraw, n, w);
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+    float a[V], b[V], c[V];
+    ldv(x0 + i * V, a);
+    ldv(x1 + i * V, b);
+    if (n > 2) ldv(x2 + i * V, c);
+#pragma unroll
+    for (int e = 0; e < V; ++e) a[e] = w[0] * a[e] + w[1] * b[e] + (n > 2 ? w[2] * c[e] : 0.f);
+    stv(out + i * V, a);
+  }
+}
+
+template <typename T>
+__global__ void fuse_sum_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ x0, const T* __restrict__ x1,
+                                    const T* __restrict__ x2, const float* __restrict__ wraw, T* __restrict__ d0,
+                                    T* __restrict__ d1, T* __restrict__ d2, float* gacc, long nvec, int n) {
+  constexpr int V = 16 / sizeof(T);
+  float w[3];
+  softmax_w(wraw, n, w);
+  float g[3] = {0.f, 0.f, 0.f};
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+    float d[V], a[V], b[V], c[V], o[V];
+    ldv(dout + i * V, d);
+    if (gacc) {
+      ldv(x0 + i * V, a);
+      ldv(x1 + i * V, b);
+      if (n > 2) ldv(x2 + i * V, c);
+#pragma unroll
+      for (int e = 0; e < V; ++e) { g[0] += d[e] * a[e]; g[1] += d[e] * b[e]; if (n > 2) g[2] += d[e] * c[e]; }
+    }
+    if (d0) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) o[e] = w[0] * d[e];
+      stv(d0 + i * V, o);
+    }
+    if (d1) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) o[e] = w[1] * d[e];
+      stv(d1 + i * V, o);
+    }
+    if (n > 2 && d2) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) o[e] = w[2] * d[e];
+      stv(d2 + i * V, o);
+    }
+  }
+  if (gacc) block_accumulate(g, n, gacc);
+}
+
+// d raw_j = w_j * (g_j - sum_i w_i g_i)  (softmax Jacobian), accumulated into dw_raw
+__global__ void fusion_wgrad_kernel(const float* wraw, const float* g, float* dw_raw, int n) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float w[3];
+    softmax_w(wraw, n, w);
+    float dot = 0.f;
+    for (int i = 0; i < n; ++i) dot += w[i] * g[i];
+    for (int j = 0; j < n; ++j) dw_raw[j] = w[j] * (g[j] - dot);
+  }
+}
+
+// ------------------------------------------------------------------ column sums: partial stage + final stage
+// mode 0: sums of (dy) and (dy * xhat)            [act -> norm, s = post-activation tensor]
+// mode 1: g = dy*act'(xhat*gamma+beta); sums of g and g*xhat   [norm -> act, s = pre-norm tensor]
+// Thread -> (channel vector cv, row lane rl): a block's rows are dealt to nrl = TPB/cvec row lanes, each of
+// which writes its own partial row: part[(block*nrl + rl)][2][C].
+template <typename T>
+__global__ void norm_bwd_reduce_kernel(const T* __restrict__ s, const T* __restrict__ dy, long rows, int C,
+                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta, int mode,
+                                       int act, float* __restrict__ part, int rows_per_block, int nrl) {
+  constexpr int V = 16 / sizeof(T);
+  const int cvec = C / V;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = min(rows, r0 + rows_per_block);
+  const int rl = threadIdx.x / cvec;
+  if (rl >= nrl) return;
+  for (int cv = threadIdx.x % cvec; cv < cvec; cv += TPB) {
+    float sb[V], sg[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) sb[e] = sg[e] = 0.f;
+    float mu[V], rs[V], ga[V], be[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const int c = cv * V + e;
+      mu[e] = mean[c]; rs[e] = rstd[c];
+      ga[e] = gamma ? gamma[c] : 1.f; be[e] = beta ? beta[c] : 0.f;
+    }
+    for (long r = r0 + rl; r < r1; r += nrl) {
+      float fs[V], fd[V];
+      ldv(s + (r * cvec + cv) * V, fs);
+      ldv(dy + (r * cvec + cv) * V, fd);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float xh = (fs[e] - mu[e]) * rs[e];
+        float g = fd[e];
+        if (mode == 1) g *= act_grad(xh * ga[e] + be[e], act);
+        sb[e] += g;
+        sg[e] += g * xh;
+      }
+    }
+    const long prow = (long)blockIdx.x * nrl + rl;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      part[(prow * 2 + 0) * C + cv * V + e] = sb[e];
+      part[(prow * 2 + 1) * C + cv * V + e] = sg[e];
+    }
+  }
+}
+
+// out[k][c] = sum_r part[r][k][c]   (k < K)
+__global__ void colsum_finalize_kernel(const float* __restrict__ part, int R, int K, int C, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= K * C) return;
+  double s = 0.0;
+  for (int r = 0; r < R; ++r) s += (double)part[(long)r * K * C + idx];
+  out[idx] = (float)s;
+}
+
+// dz for conv->act->BN (mode 0) or conv->BN->act (mode 1); batch_stats: include the mean/var terms
+template <typename T>
+__global__ void norm_bwd_apply_kernel(const T* __restrict__ s, const T* __restrict__ dy, T* __restrict__ dz, long nvec,
+                                      int cvec, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ sums /*[2][C]: dbeta, dgamma*/, float inv_count,
+                                      int mode, int act, int batch_stats) {
+  constexpr int V = 16 / sizeof(T);
+  const int C = cvec * V;
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+    const int c0 = (int)(i % cvec) * V;
+    float fs[V], fd[V];
+    ldv(s + i * V, fs);
+    ldv(dy + i * V, fd);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const int c = c0 + e;
+      const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+      const float xh = (fs[e] - mean[c]) * rstd[c];
+      float g = fd[e];
+      if (mode == 1) g *= act_grad(xh * ga + be, act);
+      float dr = g;
+      if (batch_stats) dr -= inv_count * (sums[c] + xh * sums[C + c]);
+      dr *= ga * rstd[c];
+      if (mode == 0) dr *= act_grad(fs[e], act);  // s is post-activation: relu mask from s > 0
+      fd[e] = dr;
+    }
+    stv(dz + i * V, fd);
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm + activation over rows of C
+// one wave per row; lane owns chunks lane, lane+64 (C <= 128*V)
+template <typename T>
+__global__ void layernorm_act_kernel(const T* __restrict__ z, T* __restrict__ y, long rows, int C,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                     int act, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  constexpr int V = 16 / sizeof(T);
+  const int cvec = C / V, lane = threadIdx.x & 63;
+  const long wave = ((long)blockIdx.x * TPB + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * TPB) >> 6;
+  for (long r = wave; r < rows; r += nwaves) {
+    float f[2][V];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int cv = lane + 64 * k;
+      if (cv < cvec) {
+        ldv(z + (r * cvec + cv) * V, f[k]);
+#pragma unroll
+        for (int e = 0; e < V; ++e) s += f[k][e];
+      }
+    }
+    const float mu = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (lane + 64 * k < cvec) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) { const float d = f[k][e] - mu; q += d * d; }
+      }
+    const float rs = 1.f / sqrtf(wave_sum(q) / C + eps);
+    if (lane == 0 && mean_out) { mean_out[r] = mu; rstd_out[r] = rs; }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int cv = lane + 64 * k;
+      if (cv < cvec) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const int c = cv * V + e;
+          f[k][e] = apply_act((f[k][e] - mu) * rs * gamma[c] + beta[c], act);
+        }
+        stv(y + (r * cvec + cv) * V, f[k]);
+      }
+    }
+  }
+}
+
+// dz = rstd * (gh - mean_c(gh) - xhat * mean_c(gh*xhat)), gh = dy*act'(u)*gamma ; per-wave column partials
+// part: [nwaves][2][C] (dbeta, dgamma)
+template <typename T>
+__global__ void layernorm_act_bwd_kernel(const T* __restrict__ z, const T* __restrict__ dy, T* __restrict__ dz,
+                                         long rows, int C, const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, const float* __restrict__ mean,
+                                         const float* __restrict__ rstd, int act, float* __restrict__ part) {
+  constexpr int V = 16 / sizeof(T);
+  const int cvec = C / V, lane = threadIdx.x & 63;
+  const long wave = ((long)blockIdx.x * TPB + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * TPB) >> 6;
+  float pb[2][V], pg[2][V];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int e = 0; e < V; ++e) pb[k][e] = pg[k][e] = 0.f;
+  for (long r = wave; r < rows; r += nwaves) {
+    const float mu = mean[r], rs = rstd[r];
+    float xh[2][V], gh[2][V];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int cv = lane + 64 * k;
+      if (cv < cvec) {
+        float fz[V], fd[V];
+        ldv(z + (r * cvec + cv) * V, fz);
+        ldv(dy + (r * cvec + cv) * V, fd);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const int c = cv * V + e;
+          const float x = (fz[e] - mu) * rs;
+          const float g = fd[e] * act_grad(x * gamma[c] + beta[c], act);
+          pb[k][e] += g;
+          pg[k][e] += g * x;
+          xh[k][e] = x;
+          gh[k][e] = g * gamma[c];
+          s1 += gh[k][e];
+          s2 += gh[k][e] * x;
+        }
+      }
+    }
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int cv = lane + 64 * k;
+      if (cv < cvec) {
+        float o[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = rs * (gh[k][e] - s1 - xh[k][e] * s2);
+        stv(dz + (r * cvec + cv) * V, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int cv = lane + 64 * k;
+    if (cv < cvec) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        part[(wave * 2 + 0) * C + cv * V + e] = pb[k][e];
+        part[(wave * 2 + 1) * C + cv * V + e] = pg[k][e];
+      }
+    }
+  }
+}
+
+// column sums of a [rows][C] tensor: part [nblk*nrl][C]
+template <typename T>
+__global__ void colsum_partial_kernel(const T* __restrict__ x, long rows, int C, float* __restrict__ part,
+                                      int rows_per_block, int nrl) {
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  const int rl = threadIdx.x / C;
+  if (rl >= nrl) return;
+  for (int c = threadIdx.x % C; c < C; c += TPB) {
+    float s = 0.f;
+    for (long r = r0 + rl; r < r1; r += nrl) s += elem<T>::ld(x + r * C + c);
+    part[((long)blockIdx.x * nrl + rl) * C + c] = s;
+  }
+}
+
+// [Cout][KH][KW][Cin] -> [Cin][KH][KW][Cout] with both spatial axes flipped (dgrad weights), optional dtype change
+template <typename TI, typename TO>
+__global__ void weight_flip_transpose_kernel(const TI* __restrict__ w, TO* __restrict__ o, int Cout, int KH, int KW,
+                                             int Cin, int flip) {
+  const long n = (long)Cout * KH * KW * Cin;
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) {
+    long t = i;
+    const int co = (int)(t % Cout); t /= Cout;
+    const int kx = (int)(t % KW); t /= KW;
+    const int ky = (int)(t % KH);
+    const int ci = (int)(t / KH);
+    const int sy = flip ? KH - 1 - ky : ky, sx = flip ? KW - 1 - kx : kx;
+    elem<TO>::st(o + i, elem<TI>::ld(w + (((long)co * KH + sy) * KW + sx) * Cin + ci));
+  }
+}
+
+inline int grid_for(long n) {
+  long g = (n + TPB - 1) / TPB;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+#define DISPATCH_DTYPE(dtype, ...)                                   \
+  if (dtype == SIHL_F32) { typedef float T; __VA_ARGS__; }           \
+  else if (dtype == SIHL_BF16) { typedef bf16_t T; __VA_ARGS__; }    \
+  else return SIHL_EARG;
+
+extern "C" {
+
+int sihl_bn_finalize(const float* partials, int n_partials, int C, long count, const float* gamma, const float* beta,
+                     float eps, float momentum, float* running_mean, float* running_var, float* mean, float* rstd,
+                     float* scale, float* shift, hipStream_t stream) {
+  if (!partials || n_partials <= 0 || C <= 0 || count <= 0 || !mean || !rstd || !scale || !shift) return SIHL_EARG;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, partials, n_partials, C,
+                     (double)count, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift);
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+int sihl_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                        float eps, int C, float* scale, float* shift, hipStream_t stream) {
+  if (!running_mean || !running_var || !scale || !shift || C <= 0) return SIHL_EARG;
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, gamma, beta, running_mean,
+                     running_var, eps, C, scale, shift);
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+int sihl_affine_act(const void* x, void* y, long rows, int C, const float* scale, const float* shift, int act,
+                    int dtype, hipStream_t stream) {
+  if (!x || !y || rows <= 0 || C <= 0) return SIHL_EARG;
+  DISPATCH_DTYPE(dtype, {
+    constexpr int V = 16 / sizeof(T);
+    if (C % V) return SIHL_EARG;
+    const long nvec = rows * (C / V);
+    hipLaunchKernelGGL(affine_act_kernel<T>, dim3(grid_for(nvec)), dim3(TPB), 0, stream, (const T*)x, (T*)y, nvec,
+                       C / V, scale, shift, act);
+  });
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+int sihl_affine_act_bwd(const void* x, const void* dy, void* dx, long rows, int C, const float* scale,
+                        const float* shift, int act, int dtype, hipStream_t stream) {
+  if (!x || !dy || !dx || rows <= 0 || C <= 0) return SIHL_EARG;
+  DISPATCH_DTYPE(dtype, {
+    constexpr int V = 16 / sizeof(T);
+    if (C % V) return SIHL_EARG;
+    const long nvec = rows * (C / V);
+    hipLaunchKernelGGL(affine_act_bwd_kernel<T>, dim3(grid_for(nvec)), dim3(TPB), 0, stream, (const T*)x,
+                       (const T*)dy, (T*)dx, nvec, C / V, scale, shift, act);
+  });
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+// out[N][H][W][C] = w0*bilinear_x2(a[N][H/2][W/2][C]) + w1*b ; w = softmax(wraw[0:2]); b==null -> plain upsample
+int sihl_fuse_up2(const void* a, const void* b, const float* wraw, void* out, int N, int H, int W, int C, int dtype,
+                  hipStream_t stream) {
+  if (!a || !out || N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || (b && !wraw)) return SIHL_EARG;
+  DISPATCH_DTYPE(dtype, {
+    constexpr int V = 16 / sizeof(T);
+    if (C % V) return SIHL_EARG;
+    hipLaunchKernelGGL(fuse_up2_kernel<T>, dim3(grid_for((long)N * H * W * (C / V))), dim3(TPB), 0, stream,
+                       (const T*)a, (const T*)b, wraw, (T*)out, N, H, W, C);
+  });
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+// gacc: 2 floats, zeroed by this call; da/db may be null when not needed; dw_raw (2 floats) written if non-null
+int sihl_fuse_up2_bwd(const void* dout, const void* a, const void* b, const float* wraw, void* da, void* db,
+                      float* dw_raw, float* gacc, int N, int H, int W, int C, int dtype, hipStream_t stream) {
+  if (!dout || N <= 0 || (H & 1) || (W & 1) || (dw_raw && !gacc)) return SIHL_EARG;
+  if ((db || dw_raw) && (!a || !b || !wraw)) return SIHL_EARG;  // b == null: plain upsample, only da
+  if (dw_raw) { hipError_t e = hipMemsetAsync(gacc, 0, 2 * sizeof(float), stream); if (e) return (int)e; }
+  DISPATCH_DTYPE(dtype, {
+    constexpr int V = 16 / sizeof(T);
+    if (C % V) return SIHL_EARG;
+    if (db || dw_raw)
+      hipLaunchKernelGGL(fuse_up2_bwd_hi_kernel<T>, dim3(grid_for((long)N * H * W * (C / V))), dim3(TPB), 0, stream,
+                         (const T*)dout, (const T*)a, (const T*)b, wraw, (T*)db, dw_raw ? gacc : nullptr, N, H, W, C);
+    if (da)
+      hipLaunchKernelGGL(up2_adjoint_kernel<T>, dim3(grid_for((long)N * (H / 2) * (W / 2) * (C / V))), dim3(TPB), 0,
+                         stream, (const T*)dout, b ? wraw : nullptr, (T*)da, N, H, W, C);
+  });
+  if (dw_raw) hipLaunchKernelGGL(fusion_wgrad_kernel, dim3(1), dim3(64), 0, stream, wraw, gacc, dw_raw, 2);
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+
+// out = sum_i softmax(wraw)_i * x_i over n (2 or 3) same-shaped tensors of `numel` elements
+int sihl_fuse_sum(const void* x0, const void* x1, const void* x2, const float* wraw, void* out, long numel, int n,
+                  int dtype, hipStream_t stream) {
+  if (!x0 || !x1 || (n == 3 && !x2) || !wraw || !out || numel <= 0 || n < 2 || n > 3) return SIHL_EARG;
+  DISPATCH_DTYPE(dtype, {
+    constexpr int V = 16 / sizeof(T);
+    if (numel % V) return SIHL_EARG;
+    hipLaunchKernelGGL(fuse_sum_kernel<T>, dim3(grid_for(numel / V)), dim3(TPB), 0, stream, (const T*)x0, (const T*)x1,
+                       (const T*)x2, wraw, (T*)out, numel / V, n);
+  });
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+int sihl_fuse_sum_bwd(const void* dout, const void* x0, const void* x1, const void* x2, const float* wraw, void* d0,
+                      void* d1, void* d2, float* dw_raw, float* gacc, long numel, int n, int dtype,
+                      hipStream_t stream) {
+  if (!dout || !wraw || numel <= 0 || n < 2 || n > 3 || (dw_raw && (!gacc || !x0 || !x1 || (n == 3 && !x2))))
+    return SIHL_EARG;
+  if (dw_raw) { hipError_t e = hipMemsetAsync(gacc, 0, 3 * sizeof(float), stream); if (e) return (int)e; }
+  DISPATCH_DTYPE(dtype, {
+    constexpr int V = 16 / sizeof(T);
+    if (numel % V) return SIHL_EARG;
+    hipLaunchKernelGGL(fuse_sum_bwd_kernel<T>, dim3(grid_for(numel / V)), dim3(TPB), 0, stream, (const T*)dout,
+                       (const T*)x0, (const T*)x1, (const T*)x2, wraw, (T*)d0, (T*)d1, (T*)d2,
+                       dw_raw ? gacc : nullptr, numel / V, n);
+  });
+  if (dw_raw) hipLaunchKernelGGL(fusion_wgrad_kernel, dim3(1), dim3(64), 0, stream, wraw, gacc, dw_raw, n);
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+// out[N][Ho][Wo][C] = w0*blurpool_s2(a[N][H][W][C]) + w1*b + w2*c ; b==c==null -> plain blur pool
+int sihl_blur_fuse(const void* a, const void* b, const void* c, const float* wraw, void* out, int N, int H, int W,
+                   int C, int dtype, hipStream_t stream) {
+  if (!a || !out || N <= 0 || H < 2 || W < 2 || ((b != nullptr) != (c != nullptr)) || (b && !wraw)) return SIHL_EARG;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  DISPATCH_DTYPE(dtype, {
+    constexpr int V = 16 / sizeof(T);
+    if (C % V) return SIHL_EARG;
+    hipLaunchKernelGGL(blur_fuse_kernel<T>, dim3(grid_for((long)N * Ho * Wo * (C / V))), dim3(TPB), 0, stream,
+                       (const T*)a, (const T*)b, (const T*)c, wraw, (T*)out, N, H, W, Ho, Wo, C);
+  });
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+// fused (b != null): gacc 3 floats; plain blur (b == null): only da is produced
+int sihl_blur_fuse_bwd(const void* dout, const void* a, const void* b, const void* c, const float* wraw, void* da,
+                       void* db, void* dc, float* dw_raw, float* gacc, int N, int H, int W, int C, int dtype,
+                       hipStream_t stream) {
+  if (!dout || N <= 0 || H < 2 || W < 2 || (dw_raw && (!gacc || !b))) return SIHL_EARG;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  if (dw_raw) { hipError_t e = hipMemsetAsync(gacc, 0, 3 * sizeof(float), stream); if (e) return (int)e; }
+  DISPATCH_DTYPE(dtype, {
+    constexpr int V = 16 / sizeof(T);
+    if (C % V) return SIHL_EARG;
+    if (b && (db || dc || dw_raw))
+      hipLaunchKernelGGL(blur_fuse_bwd_lo_kernel<T>, dim3(grid_for((long)N * Ho * Wo * (C / V))), dim3(TPB), 0,
+                         stream, (const T*)dout, (const T*)a, (const T*)b, (const T*)c, wraw, (T*)db, (T*)dc,
+                         dw_raw ? gacc : nullptr, N, H, W, Ho, Wo, C);
+    if (da)
+      hipLaunchKernelGGL(blur_adjoint_kernel<T>, dim3(grid_for((long)N * H * W * (C / V))), dim3(TPB), 0, stream,
+                         (const T*)dout, b ? wraw : nullptr, (T*)da, N, H, W, Ho, Wo, C);
+  });
+  if (dw_raw) hipLaunchKernelGGL(fusion_wgrad_kernel, dim3(1), dim3(64), 0, stream, wraw, gacc, dw_raw, 3);
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+// Backward through BatchNorm (+ activation).  mode 0: s = act(conv) (post-activation, pre-norm), y = BN(s);
+// mode 1: s = conv (pre-norm), y = act(BN(s)).  Writes dgamma/dbeta (fp32 [C]) and dz (grad wrt conv output).
+static int reduce_blocks(long rows) {
+  long nb = (rows + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+static int row_lanes(int threads_per_row) { return threads_per_row >= TPB ? 1 : TPB / threads_per_row; }
+
+// Workspace bytes for sihl_norm_act_bwd / sihl_colsum.
+long sihl_norm_act_bwd_ws_bytes(long rows, int C, int dtype) {
+  const int cvec = C / (dtype == SIHL_BF16 ? 8 : 4);
+  return ((long)reduce_blocks(rows) * row_lanes(cvec) * 2 * C + 2L * C) * (long)sizeof(float);
+}
+long sihl_colsum_ws_bytes(long rows, int C) { return (long)reduce_blocks(rows) * row_lanes(C) * C * (long)sizeof(float); }
+
+int sihl_norm_act_bwd(const void* s, const void* dy, void* dz, long rows, int C, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, float* dgamma, float* dbeta, int mode, int act,
+                      int batch_stats, int dtype, float* ws, long ws_bytes, hipStream_t stream) {
+  if (!s || !dy || !dz || rows <= 0 || C <= 0 || !mean || !rstd || !ws) return SIHL_EARG;
+  const int nblk = reduce_blocks(rows);
+  if (ws_bytes < sihl_norm_act_bwd_ws_bytes(rows, C, dtype)) return SIHL_EWS;
+  const int rpb = (int)((rows + nblk - 1) / nblk);
+  const int nrl = row_lanes(C / (dtype == SIHL_BF16 ? 8 : 4));
+  float* sums = ws + (long)nblk * nrl * 2 * C;
+  DISPATCH_DTYPE(dtype, {
+    constexpr int V = 16 / sizeof(T);
+    if (C % V) return SIHL_EARG;
+    hipLaunchKernelGGL(norm_bwd_reduce_kernel<T>, dim3(nblk), dim3(TPB), 0, stream, (const T*)s, (const T*)dy, rows, C,
+                       mean, rstd, gamma, beta, mode, act, ws, rpb, nrl);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, (const float*)ws,
+                       nblk * nrl, 2, C, sums);
+    const long nvec = rows * (C / V);
+    hipLaunchKernelGGL(norm_bwd_apply_kernel<T>, dim3(grid_for(nvec)), dim3(TPB), 0, stream, (const T*)s,
+                       (const T*)dy, (T*)dz, nvec, C / V, mean, rstd, gamma, beta, (const float*)sums,
+                       1.f / (float)rows, mode, act, batch_stats);
+  });
+  if (dbeta) { hipError_t e = hipMemcpyAsync(dbeta, sums, C * sizeof(float), hipMemcpyDeviceToDevice, stream); if (e) return (int)e; }
+  if (dgamma) { hipError_t e = hipMemcpyAsync(dgamma, sums + C, C * sizeof(float), hipMemcpyDeviceToDevice, stream); if (e) return (int)e; }
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+int sihl_layernorm_act(const void* z, void* y, long rows, int C, const float* gamma, const float* beta, float eps,
+                       int act, float* mean, float* rstd, int dtype, hipStream_t stream) {
+  if (!z || !y || rows <= 0 || C <= 0 || !gamma || !beta) return SIHL_EARG;
+  DISPATCH_DTYPE(dtype, {
+    constexpr int V = 16 / sizeof(T);
+    if (C % V || C / V > 128) return SIHL_EARG;
+    long g = (rows + 3) / 4;
+    if (g > 256 * 8) g = 256 * 8;
+    hipLaunchKernelGGL(layernorm_act_kernel<T>, dim3((int)g), dim3(TPB), 0, stream, (const T*)z, (T*)y, rows, C, gamma,
+                       beta, eps, act, mean, rstd);
+  });
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+int sihl_layernorm_bwd_waves(long rows) {
+  long g = (rows + 3) / 4;
+  if (g > 256 * 2) g = 256 * 2;
+  if (g < 1) g = 1;
+  return (int)g * 4;
+}
+
+long sihl_layernorm_act_bwd_ws_bytes(long rows, int C) {
+  return ((long)sihl_layernorm_bwd_waves(rows) * 2 * C + 2L * C) * (long)sizeof(float);
+}
+
+// ws: sihl_layernorm_act_bwd_ws_bytes(rows, C)
+int sihl_layernorm_act_bwd(const void* z, const void* dy, void* dz, long rows, int C, const float* gamma,
+                           const float* beta, const float* mean, const float* rstd, int act, float* dgamma,
+                           float* dbeta, int dtype, float* ws, long ws_bytes, hipStream_t stream) {
+  if (!z || !dy || !dz || rows <= 0 || !gamma || !beta || !mean || !rstd || !ws) return SIHL_EARG;
+  const int nwaves = sihl_layernorm_bwd_waves(rows);
+  if (ws_bytes < (long)(nwaves * 2L * C + 2L * C) * (long)sizeof(float)) return SIHL_EWS;
+  float* sums = ws + (long)nwaves * 2 * C;
+  DISPATCH_DTYPE(dtype, {
+    constexpr int V = 16 / sizeof(T);
+    if (C % V || C / V > 128) return SIHL_EARG;
+    hipLaunchKernelGGL(layernorm_act_bwd_kernel<T>, dim3(nwaves / 4), dim3(TPB), 0, stream, (const T*)z, (const T*)dy,
+                       (T*)dz, rows, C, gamma, beta, mean, rstd, act, ws);
+  });
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, (const float*)ws, nwaves,
+                     2, C, sums);
+  if (dbeta) { hipError_t e = hipMemcpyAsync(dbeta, sums, C * sizeof(float), hipMemcpyDeviceToDevice, stream); if (e) return (int)e; }
+  if (dgamma) { hipError_t e = hipMemcpyAsync(dgamma, sums + C, C * sizeof(float), hipMemcpyDeviceToDevice, stream); if (e) return (int)e; }
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+// out[c] = sum_r x[r][c]   (bias gradients).  ws: sihl_colsum_ws_bytes(rows, C)
+int sihl_colsum(const void* x, long rows, int C, float* out, int dtype, float* ws, long ws_bytes, hipStream_t stream) {
+  if (!x || !out || rows <= 0 || C <= 0 || !ws) return SIHL_EARG;
+  const int nblk = reduce_blocks(rows), nrl = row_lanes(C);
+  if (ws_bytes < sihl_colsum_ws_bytes(rows, C)) return SIHL_EWS;
+  const int rpb = (int)((rows + nblk - 1) / nblk);
+  DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL(colsum_partial_kernel<T>, dim3(nblk), dim3(TPB), 0, stream, (const T*)x, rows, C, ws, rpb, nrl);
+  });
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)ws,
+                     nblk * nrl, 1, C, out);
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+// w [Cout][KH][KW][Cin] (dtype_in) -> o [Cin][KH][KW][Cout] (dtype_out), spatially flipped when flip != 0
+int sihl_weight_flip_transpose(const void* w, void* o, int Cout, int KH, int KW, int Cin, int flip, int dtype_in,
+                               int dtype_out, hipStream_t stream) {
+  if (!w || !o || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return SIHL_EARG;
+  const int g = grid_for((long)Cout * KH * KW * Cin);
+  if (dtype_in == SIHL_F32 && dtype_out == SIHL_F32)
+    hipLaunchKernelGGL((weight_flip_transpose_kernel<float, float>), dim3(g), dim3(TPB), 0, stream, (const float*)w, (float*)o, Cout, KH, KW, Cin, flip);
+  else if (dtype_in == SIHL_F32 && dtype_out == SIHL_BF16)
+    hipLaunchKernelGGL((weight_flip_transpose_kernel<float, bf16_t>), dim3(g), dim3(TPB), 0, stream, (const float*)w, (bf16_t*)o, Cout, KH, KW, Cin, flip);
+  else if (dtype_in == SIHL_BF16 && dtype_out == SIHL_BF16)
+    hipLaunchKernelGGL((weight_flip_transpose_kernel<bf16_t, bf16_t>), dim3(g), dim3(TPB), 0, stream, (const bf16_t*)w, (bf16_t*)o, Cout, KH, KW, Cin, flip);
+  else return SIHL_EARG;
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+}  // extern "C"

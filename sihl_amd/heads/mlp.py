@@ -1,0 +1,52 @@
+"""torchvision.ops.MLP mirror (Linear -> LayerNorm -> SiLU -> Dropout, ..., Linear -> Dropout) whose
+forward runs the HIP linear (matrix-core 1x1) and LayerNorm+SiLU kernels.  Same 18-module layout and
+state_dict keys as the reference's heads (src/sihl/heads/object_detection.py:51-61)."""
+from typing import List
+
+from torch import Tensor, nn
+
+from sihl_amd import ops
+
+
+class MLP(nn.Sequential):
+    def __init__(self, in_channels: int, hidden_channels: List[int], norm_layer=None, activation_layer=nn.ReLU,
+                 inplace=None, bias=True, dropout=0.0):
+        kw = {} if inplace is None else {"inplace": inplace}
+        mods: List[nn.Module] = []
+        d = in_channels
+        for h in hidden_channels[:-1]:
+            mods.append(nn.Linear(d, h, bias=bias))
+            if norm_layer is not None:
+                mods.append(norm_layer(h))
+            mods.append(activation_layer(**kw))
+            mods.append(nn.Dropout(dropout, **kw))
+            d = h
+        mods.append(nn.Linear(d, hidden_channels[-1], bias=bias))
+        mods.append(nn.Dropout(dropout, **kw))
+        super().__init__(*mods)
+
+    def forward(self, x: Tensor) -> Tensor:
+        """x: (..., C) -> (..., out); runs over flattened rows."""
+        lead = x.shape[:-1]
+        h = x.reshape(-1, x.shape[-1])
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Linear):
+                h = ops.linear(h, m.weight, m.bias)
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                if isinstance(nxt, nn.LayerNorm):
+                    act = mods[i + 2]
+                    if not isinstance(act, nn.SiLU):
+                        raise NotImplementedError("LayerNorm is fused with SiLU only")
+                    h = ops.layernorm_act(h, nxt.weight, nxt.bias, nxt.eps, "silu")
+                    i += 3
+                    continue
+            elif isinstance(m, nn.Dropout):
+                if m.p != 0.0 and self.training:
+                    raise NotImplementedError("dropout > 0 is outside the HIP hot path")
+            else:
+                raise NotImplementedError(f"unsupported MLP layer {type(m).__name__}")
+            i += 1
+        return h.reshape(*lead, h.shape[-1])

@@ -1,0 +1,172 @@
+"""ObjectDetection head on the HIP path (reference src/sihl/heads/object_detection.py:14-217,252-284).
+
+forward: per-level 1x1 conv+BN laterals written straight into the flat (B, P, C) position buffer ->
+loc MLP over all P positions -> per-image top-K (LDS bitonic sort) -> gather K rows -> class / box
+MLPs on K rows -> fused sigmoid / argmax / closed-form-anchor box decode.
+training_step: same laterals + MLPs (matrix-core kernels with hand-written backward); anchor
+matching and the four losses are fp32 device ops, as in the reference's autocast-disabled islands.
+"""
+from functools import partial
+from typing import Dict, List, Tuple
+
+import torch
+from torch import Tensor, nn
+from torch.nn import functional as F
+
+from sihl_amd import ops
+from sihl_amd.heads.box_ops import complete_box_iou, complete_box_iou_loss
+from sihl_amd.heads.mlp import MLP
+from sihl_amd.layers.convblocks import Conv2dNormActivation
+
+
+class ObjectDetection(nn.Module):
+    def __init__(self, in_channels: List[int], num_classes: int, bottom_level: int = 3, top_level: int = 5,
+                 num_channels: int = 256, num_layers: int = 4, max_instances: int = 100) -> None:
+        assert num_classes > 0, num_classes
+        assert len(in_channels) > top_level, (len(in_channels), top_level)
+        assert 0 < bottom_level <= top_level, (bottom_level, top_level)
+        assert num_channels % 4 == 0, num_channels
+        assert num_layers >= 0, num_layers
+        assert max_instances > 0, max_instances
+        super().__init__()
+        self.in_channels = in_channels
+        self.num_classes = num_classes
+        self.bottom_level, self.top_level = bottom_level, top_level
+        self.levels = range(bottom_level, top_level + 1)
+        self.num_channels, self.num_layers = num_channels, num_layers
+        self.max_instances = max_instances
+        self.topk = 9
+        mlp = partial(MLP, norm_layer=nn.LayerNorm, activation_layer=nn.SiLU)
+        self.laterals = nn.ModuleList(
+            [Conv2dNormActivation(in_channels[l], num_channels, 1, activation_layer=None) for l in self.levels])
+        hidden = [num_channels] * num_layers
+        self.loc_head = mlp(num_channels, hidden + [1])
+        self.loc_head[-2].bias.data.fill_(-5.0)  # reference :58
+        self.cls_head = mlp(num_channels, hidden + [num_classes])
+        self.box_head = mlp(num_channels, hidden + [4])
+        self.iou_head = mlp(num_channels, hidden + [1])
+        self.output_shapes = {
+            "num_instances": ("batch_size",),
+            "scores": ("batch_size", max_instances),
+            "classes": ("batch_size", max_instances),
+            "boxes": ("batch_size", max_instances, 4),
+        }
+
+    # ------------------------------------------------------------------ helpers
+    def _level_hw(self, inputs: List[Tensor]) -> List[Tuple[int, int]]:
+        return [tuple(inputs[l].shape[2:]) for l in self.levels]
+
+    def get_offsets_and_scales(self, inputs: List[Tensor]) -> Tuple[Tensor, Tensor]:
+        return ops.od_anchors(self._level_hw(inputs), inputs[self.bottom_level].device)
+
+    def _flat_feats(self, inputs: List[Tensor]) -> Tensor:
+        """(B, P, C) lateral features, positions in level-major, row-major order (reference :102-105)."""
+        feats = [lat.forward_nhwc(ops.nhwc(inputs[l])) for l, lat in zip(self.levels, self.laterals)]
+        B, C = feats[0].shape[0], feats[0].shape[-1]
+        return torch.cat([f.reshape(B, -1, C) for f in feats], dim=1)
+
+    # ------------------------------------------------------------------ inference
+    def forward(self, inputs: List[Tensor]) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+        B, _, H, W = inputs[0].shape
+        level_hw = self._level_hw(inputs)
+        flat = self._flat_feats(inputs)
+        P, K = flat.shape[1], self.max_instances
+        loc_logits = self.loc_head(flat.view(B * P, -1))  # (B*P, 1) view of a vector-padded buffer
+        top_vals, top_idx = ops.topk_rows(loc_logits, B, P, K, estride=loc_logits.stride(0))
+        sel = ops.gather_rows(flat, top_idx)
+        cls_logits = self.cls_head(sel.view(B * K, -1)).reshape(B, K, -1)
+        box_raw = self.box_head(sel.view(B * K, -1)).reshape(B, K, 4)
+        return ops.od_decode(top_vals, top_idx, cls_logits, box_raw, level_hw, (W, H))
+
+    def get_saliency(self, inputs: List[Tensor]) -> Tensor:
+        B, _, fh, fw = inputs[self.bottom_level].shape
+        out = torch.zeros((B, fh, fw), device=inputs[self.bottom_level].device)
+        for lat, l in zip(self.laterals, self.levels):
+            h, w = inputs[l].shape[2:]
+            f = lat.forward_nhwc(ops.nhwc(inputs[l]))
+            s = self.loc_head(f.reshape(B * h * w, -1)).float().sigmoid().reshape(B, 1, h, w)
+            out = torch.maximum(out, F.interpolate(s, size=(fh, fw)).squeeze(1))
+        return out
+
+    # ------------------------------------------------------------------ training
+    def training_step(self, inputs: List[Tensor], classes: List[Tensor], boxes: List[Tensor],
+                      is_validating: bool = False) -> Tuple[Tensor, Dict[str, float]]:
+        assert len(inputs) > self.top_level, "too few input levels"
+        device = inputs[self.bottom_level].device
+        B, _, H, W = inputs[0].shape
+        full = torch.tensor([[W, H, W, H]], device=device, dtype=torch.float32)
+        offsets, scales = self.get_offsets_and_scales(inputs)
+        anchors = (offsets + scales) * full
+        boxes = [b.to(device) for b in boxes]
+        classes = [c.to(device) for c in classes]
+        matches = [self.bbox_matching(anchors, boxes[b], self.topk, relative=True) for b in range(B)]
+        assignment = torch.stack([m[0] for m in matches])
+        rel_iou = torch.stack([m[1] for m in matches])
+
+        flat = self._flat_feats(inputs)
+        P, C = flat.shape[1], flat.shape[2]
+        loc_logits = self.loc_head(flat.view(B * P, C)).reshape(B, P)
+        loc_target = (rel_iou == 1.0).to(torch.float32)
+        loc_loss = F.binary_cross_entropy_with_logits(loc_logits.float(), loc_target, reduction="none")
+        loc_loss = loc_loss.sum() / loc_target.sum()
+        if rel_iou.max() == 0:
+            z = torch.zeros_like(loc_loss)
+            return loc_loss, {"location_loss": loc_loss, "box_loss": z, "class_loss": z, "iou_loss": z}
+
+        iou_preds = self.iou_head(flat.view(B * P, C)).reshape(B, P)
+        iou_loss = F.mse_loss(iou_preds.float(), rel_iou, reduction="none").sum() / rel_iou.sum()
+
+        mask = rel_iou > 0
+        wts = rel_iou[mask]
+        sel = flat[mask]
+        pos = mask.nonzero()  # (n, 2): image, position - same row-major order as boolean indexing
+        off_sel, scl_sel = offsets[pos[:, 1]], scales[pos[:, 1]]
+        gt_idx = assignment[mask]
+        gt_off = torch.tensor([0] + [len(b) for b in boxes[:-1]], device=device).cumsum(0)
+        flat_gt = gt_off[pos[:, 0]] + gt_idx
+        all_boxes = torch.cat(boxes).to(torch.float32)
+        all_classes = torch.cat(classes)
+
+        box_preds = off_sel + scl_sel * self.box_head(sel).float().exp()
+        box_loss = complete_box_iou_loss(box_preds, all_boxes[flat_gt] / full)
+        box_loss = (wts * box_loss).sum() / wts.sum()
+
+        cls_logits = self.cls_head(sel)
+        cls_loss = F.cross_entropy(cls_logits.float(), all_classes[flat_gt], reduction="none")
+        cls_loss = (wts * cls_loss).sum() / wts.sum()
+
+        loss = loc_loss + 10 * box_loss + cls_loss + iou_loss
+        return loss, {"location_loss": loc_loss, "box_loss": box_loss, "class_loss": cls_loss,
+                      "iou_loss": iou_loss}
+
+    def on_validation_start(self) -> None:
+        self._val_losses: List[Tensor] = []
+
+    def validation_step(self, inputs, classes, boxes):
+        loss, metrics = self.training_step(inputs, classes, boxes, is_validating=True)
+        self._val_losses.append(loss.detach())
+        return loss, metrics
+
+    def on_validation_end(self) -> Dict[str, float]:
+        # box mAP needs a COCO evaluator (torchmetrics + faster_coco_eval in the reference): out of scope
+        return {"loss": torch.stack(self._val_losses).mean().item() if self._val_losses else float("nan")}
+
+    @staticmethod
+    def bbox_matching(anchors: Tensor, gt_boxes: Tensor, topk: int, relative: bool = False):
+        """Top-k-per-GT one-to-many assignment (reference :252-284)."""
+        A, G = anchors.shape[0], gt_boxes.shape[0]
+        assign = torch.full((A,), -1, device=anchors.device)
+        o2m = torch.zeros((A,), device=anchors.device)
+        if G == 0:
+            return assign, o2m
+        ious = complete_box_iou(anchors, gt_boxes.to(anchors.dtype)).clamp(0)
+        top_v, top_i = torch.topk(ious, k=topk, dim=0)
+        in_topk = torch.zeros((A, G), dtype=torch.bool, device=anchors.device)
+        in_topk.scatter_(0, top_i, True)
+        best_iou, best_gt = torch.max(ious * in_topk.float(), dim=1)
+        valid = in_topk.any(dim=1)
+        assign = torch.where(valid, best_gt, assign)
+        if not relative:
+            return assign, torch.where(valid, best_iou, o2m)
+        rel = (best_iou / top_v[0][best_gt]).nan_to_num(0)
+        return assign, torch.where(valid, rel, o2m)

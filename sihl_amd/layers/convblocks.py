@@ -1,0 +1,150 @@
+"""ConvNormAct / SequentialConvBlocks / Conv2dNormActivation on the HIP path.
+
+Mirrors src/sihl/layers/convblocks.py:37-117 of the reference (and torchvision's
+ops.Conv2dNormActivation used by fpn.py:26-37 / heads/object_detection.py:52-55): same constructor
+arguments, same child-module indices and therefore the same ``state_dict`` keys and shapes, so a
+reference checkpoint loads key-for-key.  The children (nn.Conv2d / nn.BatchNorm2d) are parameter
+containers only - ``forward`` runs the fused HIP kernels in ``sihl_amd.ops``.
+"""
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from sihl_amd import ops
+
+_ACT_MODULES = {
+    "relu": lambda: nn.ReLU(inplace=True),
+    "silu": lambda: nn.SiLU(inplace=True),
+    "sigmoid": nn.Sigmoid,
+}
+
+
+def _vec(dtype) -> int:
+    return 8 if dtype == torch.bfloat16 else 4
+
+
+def _pad_to(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+class _ConvBlock(nn.Sequential):
+    """Shared forward for conv->act->norm ("act_norm") and conv->norm->act ("norm_act")."""
+
+    order = "act_norm"
+    act: Optional[str] = None
+
+    def _parts(self):
+        conv = self[0]
+        norm = next((m for m in self if isinstance(m, nn.BatchNorm2d)), None)
+        return conv, norm
+
+    def forward_nhwc(self, x: Tensor) -> Tensor:
+        conv, bn = self._parts()
+        if conv.groups != 1 or conv.padding_mode != "zeros":
+            raise NotImplementedError("sihl_amd conv kernels cover groups=1, zero padding")
+        if any(isinstance(m, (nn.GroupNorm, nn.Softplus, nn.Softmax)) for m in self):
+            raise NotImplementedError("GroupNorm / softplus / softmax blocks are outside the HIP hot path")
+        (sh, sw), (ph, pw), (dh, dw) = conv.stride, conv.padding, conv.dilation
+        if sh != sw or ph != pw or dh != dw:
+            raise NotImplementedError("square stride / padding / dilation only")
+        weight, bias = conv.weight, conv.bias
+        vec = _vec(x.dtype)
+        cout = weight.shape[0]
+        # zero-pad odd channel counts up to the 16-byte vector width (tiny convs only: UAFM 4->1, classifiers)
+        if x.shape[-1] % vec:
+            padc = _pad_to(x.shape[-1], vec) - x.shape[-1]
+            x = F.pad(x, (0, padc))
+            weight = F.pad(weight, (0, 0, 0, 0, 0, padc))
+        if cout % vec:
+            if bn is not None:
+                raise NotImplementedError("normalised conv needs Cout to be a multiple of the vector width")
+            weight = F.pad(weight, (0, 0, 0, 0, 0, 0, 0, _pad_to(cout, vec) - cout))
+            bias = F.pad(bias, (0, _pad_to(cout, vec) - cout)) if bias is not None else None
+        if bn is not None:
+            if bn.momentum is None or not bn.track_running_stats or not bn.affine:
+                raise NotImplementedError("BatchNorm2d with default affine / running-stat settings only")
+            if self.training:
+                bn.num_batches_tracked += 1
+            y = ops.conv_block(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, stride=sh,
+                               pad=ph, dil=dh, act=self.act, order=self.order, training=self.training, eps=bn.eps,
+                               momentum=bn.momentum)
+        else:
+            y = ops.conv_block(x, weight, bias, None, None, None, None, stride=sh, pad=ph, dil=dh, act=self.act)
+        return y if y.shape[-1] == cout else y[..., :cout]
+
+    def forward(self, x: Tensor) -> Tensor:
+        return ops.nchw_view(self.forward_nhwc(ops.nhwc(x)))
+
+
+class ConvNormAct(_ConvBlock):
+    """conv -> activation -> norm (note the order), reference convblocks.py:37-87."""
+
+    order = "act_norm"
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, dilation=1, groups=1, padding=None,
+                 norm="batch", act="relu", bias=None):
+        pad = padding or ((kernel_size - 1) // 2 * dilation)  # padding=0 falls through, as in the reference
+        use_bias = (norm is None) if bias is None else bool(bias)
+        mods: List[nn.Module] = [nn.Conv2d(in_channels, out_channels, kernel_size, stride, pad, dilation=dilation,
+                                           groups=groups, bias=use_bias)]
+        if act is not None:
+            if act not in _ACT_MODULES:
+                raise NotImplementedError(f"activation {act!r} is outside the HIP hot path")
+            mods.append(_ACT_MODULES[act]())
+        if norm == "batch":
+            mods.append(nn.BatchNorm2d(out_channels))
+        elif norm is not None:
+            raise NotImplementedError(f"norm {norm!r} is outside the HIP hot path")
+        super().__init__(*mods)
+        self.act = act
+
+
+class Conv2dNormActivation(_ConvBlock):
+    """torchvision.ops.Conv2dNormActivation: conv(bias=False) -> BatchNorm -> activation."""
+
+    order = "norm_act"
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=None, groups=1,
+                 norm_layer=nn.BatchNorm2d, activation_layer=nn.ReLU, dilation=1, inplace=True, bias=None):
+        if padding is None:
+            padding = (kernel_size - 1) // 2 * dilation
+        if bias is None:
+            bias = norm_layer is None
+        mods: List[nn.Module] = [nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding,
+                                           dilation=dilation, groups=groups, bias=bias)]
+        if norm_layer is not None:
+            if norm_layer is not nn.BatchNorm2d:
+                raise NotImplementedError("BatchNorm2d only")
+            mods.append(norm_layer(out_channels))
+        act = None
+        if activation_layer is not None:
+            act = {nn.ReLU: "relu", nn.SiLU: "silu", nn.Sigmoid: "sigmoid"}.get(activation_layer)
+            if act is None:
+                raise NotImplementedError(f"{activation_layer} is outside the HIP hot path")
+            mods.append(activation_layer(inplace=inplace) if activation_layer is not nn.Sigmoid else nn.Sigmoid())
+        super().__init__(*mods)
+        self.act = act
+        self.out_channels = out_channels
+
+
+class SequentialConvBlocks(nn.Sequential):
+    """reference convblocks.py:96-117"""
+
+    def __init__(self, in_channels, out_channels, num_layers, kernel_size=3, **kw):
+        if num_layers <= 0:
+            super().__init__(nn.Identity())
+            return
+        chans = [in_channels] + [out_channels] * num_layers
+        super().__init__(*[ConvNormAct(chans[i], chans[i + 1], kernel_size=kernel_size, **kw)
+                           for i in range(num_layers)])
+
+    def forward_nhwc(self, x: Tensor) -> Tensor:
+        for m in self:
+            if not isinstance(m, nn.Identity):
+                x = m.forward_nhwc(x)
+        return x
+
+    def forward(self, x: Tensor) -> Tensor:
+        return ops.nchw_view(self.forward_nhwc(ops.nhwc(x)))

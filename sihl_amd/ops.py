@@ -1,0 +1,550 @@
+"""Device ops of the sihl hot path: thin wrappers over the C-ABI + ``torch.autograd.Function`` glue.
+
+PyTorch is plumbing here (device memory from the caching allocator, the current HIP stream,
+autograd bookkeeping); every forward/backward computation below is a hand-written HIP kernel from
+``libsihl_hip.so``.  Activations are NHWC in memory (``torch.channels_last`` for the NCHW-logical
+tensors the reference API exchanges), fp32 or bf16; statistics, weights' gradients and norm
+parameters are fp32.
+"""
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from sihl_amd import _C
+from sihl_amd._C import ACT, BF16, F32, check
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _dt(t: Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"sihl_amd ops support float32 and bfloat16 activations, got {t.dtype}") from None
+
+
+def _require_gpu(t: Tensor) -> None:
+    if not t.is_cuda:
+        raise RuntimeError("sihl_amd ops run on a HIP device only (no CPU fallback); got a CPU tensor")
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_WS = {}
+
+
+def workspace(nbytes: int, device) -> Tensor:
+    """Grow-only scratch buffer per device (kernels are stream-ordered, so one buffer is shared)."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def nhwc(x: Tensor) -> Tensor:
+    """(N,C,H,W)-logical tensor -> contiguous (N,H,W,C) view (copies only if not channels_last)."""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw_view(x_nhwc: Tensor) -> Tensor:
+    return x_nhwc.permute(0, 3, 1, 2)
+
+
+def weight_khwc(w: Tensor, dtype: torch.dtype) -> Tensor:
+    """(O,I,KH,KW) parameter -> contiguous [O][KH][KW][I] in the compute dtype."""
+    return w.detach().permute(0, 2, 3, 1).to(dtype).contiguous()
+
+
+# ----------------------------------------------------------------------------- raw kernels
+def conv2d_raw(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, stride: int = 1, pad: int = 0, dil: int = 1,
+               act: Optional[str] = None, pre: Optional[Tuple[Tensor, Tensor]] = None,
+               post: Optional[Tuple[Tensor, Tensor]] = None, stats_mode: int = 0,
+               out: Optional[Tensor] = None, out_image_stride: int = 0):
+    """x (N,H,W,Cin) contiguous, w (Cout,KH,KW,Cin) contiguous, same dtype.  Returns (y, stats) with
+    stats = fp32 [rows][2][Cout] partial sums when stats_mode != 0."""
+    _require_gpu(x)
+    N, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w.shape
+    Ho = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+    if out is None:
+        out = torch.empty((N, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+    stats, stats_bytes = None, 0
+    if stats_mode:
+        rows = _C.lib().sihl_conv2d_stat_rows(N * Ho * Wo)
+        stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
+        stats_bytes = stats.numel() * 4
+    rc = _C.lib().sihl_conv2d_fwd(
+        _p(x), _p(w), _p(bias), _p(out), N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x), ACT[act],
+        _p(pre[0]) if pre else None, _p(pre[1]) if pre else None,
+        _p(post[0]) if post else None, _p(post[1]) if post else None,
+        stats_mode, _p(stats), stats_bytes, out_image_stride, _stream())
+    check(rc, "sihl_conv2d_fwd")
+    return out, stats
+
+
+def conv2d_wgrad_raw(x: Tensor, dout: Tensor, KH: int, KW: int, stride: int, pad: int, dil: int) -> Tensor:
+    """Returns fp32 dW [Cout][KH][KW][Cin]."""
+    N, H, W, Cin = x.shape
+    Cout = dout.shape[-1]
+    lib = _C.lib()
+    nbytes = lib.sihl_conv2d_wgrad_ws_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x))
+    ws = workspace(nbytes, x.device)
+    dw = torch.empty((Cout, KH, KW, Cin), dtype=torch.float32, device=x.device)
+    rc = lib.sihl_conv2d_wgrad(_p(x), _p(dout), _p(dw), N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x), 0,
+                               _p(ws), ws.numel(), _stream())
+    check(rc, "sihl_conv2d_wgrad")
+    return dw
+
+
+def weight_for_dgrad(w: Tensor, flip: bool) -> Tensor:
+    """[Cout][KH][KW][Cin] -> [Cin][KH][KW][Cout] (spatially flipped for conv dgrad), same dtype."""
+    Cout, KH, KW, Cin = w.shape
+    o = torch.empty((Cin, KH, KW, Cout), dtype=w.dtype, device=w.device)
+    rc = _C.lib().sihl_weight_flip_transpose(_p(w), _p(o), Cout, KH, KW, Cin, int(flip), _dt(w), _dt(w), _stream())
+    check(rc, "sihl_weight_flip_transpose")
+    return o
+
+
+def bn_finalize(stats: Tensor, count: int, gamma, beta, eps, momentum, running_mean, running_var):
+    C = stats.shape[-1]
+    dev = stats.device
+    mean, rstd, scale, shift = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4))
+    rc = _C.lib().sihl_bn_finalize(_p(stats), stats.shape[0], C, count, _p(gamma), _p(beta), eps, momentum,
+                                   _p(running_mean), _p(running_var), _p(mean), _p(rstd), _p(scale), _p(shift),
+                                   _stream())
+    check(rc, "sihl_bn_finalize")
+    return mean, rstd, scale, shift
+
+
+def bn_eval_affine(gamma, beta, running_mean, running_var, eps):
+    C = running_mean.numel()
+    scale = torch.empty(C, dtype=torch.float32, device=running_mean.device)
+    shift = torch.empty_like(scale)
+    rc = _C.lib().sihl_bn_eval_affine(_p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, C, _p(scale),
+                                      _p(shift), _stream())
+    check(rc, "sihl_bn_eval_affine")
+    return scale, shift
+
+
+def affine_act(x: Tensor, scale, shift, act) -> Tensor:
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    rc = _C.lib().sihl_affine_act(_p(x), _p(y), x.numel() // C, C, _p(scale), _p(shift), ACT[act], _dt(x), _stream())
+    check(rc, "sihl_affine_act")
+    return y
+
+
+def affine_act_bwd(x: Tensor, dy: Tensor, scale, shift, act) -> Tensor:
+    C = x.shape[-1]
+    dx = torch.empty_like(x)
+    rc = _C.lib().sihl_affine_act_bwd(_p(x), _p(dy), _p(dx), x.numel() // C, C, _p(scale), _p(shift), ACT[act],
+                                      _dt(x), _stream())
+    check(rc, "sihl_affine_act_bwd")
+    return dx
+
+
+def norm_act_bwd(s: Tensor, dy: Tensor, mean, rstd, gamma, beta, mode: int, act, batch_stats: bool):
+    C = s.shape[-1]
+    rows = s.numel() // C
+    lib = _C.lib()
+    ws = workspace(lib.sihl_norm_act_bwd_ws_bytes(rows, C, _dt(s)), s.device)
+    dz = torch.empty_like(s)
+    dgamma = torch.empty(C, dtype=torch.float32, device=s.device)
+    dbeta = torch.empty_like(dgamma)
+    rc = lib.sihl_norm_act_bwd(_p(s), _p(dy), _p(dz), rows, C, _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dgamma),
+                               _p(dbeta), mode, ACT[act], int(batch_stats), _dt(s), _p(ws), ws.numel(), _stream())
+    check(rc, "sihl_norm_act_bwd")
+    return dz, dgamma, dbeta
+
+
+def colsum(x: Tensor) -> Tensor:
+    C = x.shape[-1]
+    rows = x.numel() // C
+    lib = _C.lib()
+    ws = workspace(lib.sihl_colsum_ws_bytes(rows, C), x.device)
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    rc = lib.sihl_colsum(_p(x), rows, C, _p(out), _dt(x), _p(ws), ws.numel(), _stream())
+    check(rc, "sihl_colsum")
+    return out
+
+
+# ----------------------------------------------------------------------------- conv (+norm +act) block
+class ConvBlockFn(torch.autograd.Function):
+    """conv -> act -> BN ("act_norm", ConvNormAct), conv -> BN -> act ("norm_act", torchvision's
+    Conv2dNormActivation) or conv(+bias) -> act (no norm), NHWC in and out."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, cfg):
+        stride, pad, dil, act, order, has_norm, training, eps, momentum = cfg
+        xd = x.detach()
+        w = weight_khwc(weight, xd.dtype)
+        KH, KW = w.shape[1], w.shape[2]
+        need_grad = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)
+        ctx.cfg, ctx.has_norm, ctx.kshape = cfg, has_norm, (KH, KW)
+        ctx.has_bias = bias is not None
+        if not has_norm:
+            fused_ok = act in (None, "none", "relu")
+            if fused_ok or not need_grad:
+                y, _ = conv2d_raw(xd, w, bias, stride, pad, dil, act=act)
+                ctx.save_for_backward(xd, w, y if act == "relu" else None)
+                ctx.kind = "fused_act"
+            else:  # silu / sigmoid with grad: keep the pre-activation
+                z, _ = conv2d_raw(xd, w, bias, stride, pad, dil)
+                y = affine_act(z, None, None, act)
+                ctx.save_for_backward(xd, w, z)
+                ctx.kind = "split_act"
+            return y
+        mode = 0 if order == "act_norm" else 1
+        ctx.mode = mode
+        if training:
+            # one conv pass producing the pre-norm tensor + per-channel partial sums
+            s, stats = conv2d_raw(xd, w, bias, stride, pad, dil, act=act if mode == 0 else None,
+                                  stats_mode=2 if mode == 0 else 1)
+            count = s.numel() // s.shape[-1]
+            mean, rstd, scale, shift = bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean,
+                                                   running_var)
+            y = affine_act(s, scale, shift, None if mode == 0 else act)
+            ctx.batch_stats = True
+        else:
+            scale, shift = bn_eval_affine(gamma, beta, running_mean, running_var, eps)
+            if not need_grad:
+                if mode == 0:
+                    y, _ = conv2d_raw(xd, w, bias, stride, pad, dil, act=act, post=(scale, shift))
+                else:
+                    y, _ = conv2d_raw(xd, w, bias, stride, pad, dil, act=act, pre=(scale, shift))
+                return y
+            s, _ = conv2d_raw(xd, w, bias, stride, pad, dil, act=act if mode == 0 else None)
+            y = affine_act(s, scale, shift, None if mode == 0 else act)
+            mean = running_mean.detach().clone()
+            rstd = torch.rsqrt(running_var.detach() + eps)
+            ctx.batch_stats = False
+        ctx.save_for_backward(xd, w, s, mean, rstd, gamma.detach() if gamma is not None else None,
+                              beta.detach() if beta is not None else None)
+        ctx.kind = "norm"
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        stride, pad, dil, act, order, has_norm, training, eps, momentum = ctx.cfg
+        KH, KW = ctx.kshape
+        dy = dy.contiguous()
+        dgamma = dbeta = None
+        if ctx.kind == "norm":
+            x, w, s, mean, rstd, gamma, beta = ctx.saved_tensors
+            dz, dgamma, dbeta = norm_act_bwd(s, dy, mean, rstd, gamma, beta, ctx.mode, act, ctx.batch_stats)
+        elif ctx.kind == "split_act":
+            x, w, z = ctx.saved_tensors
+            dz = affine_act_bwd(z, dy, None, None, act)
+        else:
+            x, w, y = ctx.saved_tensors
+            dz = affine_act_bwd(y, dy, None, None, "relu") if y is not None else dy
+        dbias = colsum(dz) if ctx.has_bias else None
+        dw = dx = None
+        if ctx.needs_input_grad[1]:
+            dw = conv2d_wgrad_raw(x, dz, KH, KW, stride, pad, dil).permute(0, 3, 1, 2)  # (O,I,KH,KW) view
+        if ctx.needs_input_grad[0]:
+            if stride != 1:
+                raise NotImplementedError("input gradient of a strided convolution is not implemented yet")
+            wt = weight_for_dgrad(w, flip=True)
+            dx, _ = conv2d_raw(dz, wt, None, 1, dil * (KH - 1) - pad, dil)
+        return dx, dw, dbias, dgamma, dbeta, None, None, None
+
+
+def conv_block(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, *, stride=1, pad=0, dil=1, act=None,
+               order="act_norm", training=False, eps=1e-5, momentum=0.1):
+    has_norm = running_mean is not None
+    cfg = (stride, pad, dil, act, order, has_norm, training, eps, momentum)
+    return ConvBlockFn.apply(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, cfg)
+
+
+# ----------------------------------------------------------------------------- fusion nodes
+class FuseUp2Fn(torch.autograd.Function):
+    """out = softmax(w)[0] * bilinear_x2(a) + softmax(w)[1] * b   (NHWC)."""
+
+    @staticmethod
+    def forward(ctx, a, b, wraw):
+        a, b, wr = a.detach().contiguous(), b.detach().contiguous(), wraw.detach().float().contiguous()
+        N, H, W, C = b.shape
+        out = torch.empty_like(b)
+        rc = _C.lib().sihl_fuse_up2(_p(a), _p(b), _p(wr), _p(out), N, H, W, C, _dt(b), _stream())
+        check(rc, "sihl_fuse_up2")
+        ctx.save_for_backward(a, b, wr)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, b, wr = ctx.saved_tensors
+        dout = dout.contiguous()
+        N, H, W, C = b.shape
+        need_a, need_b, need_w = ctx.needs_input_grad
+        da = torch.empty_like(a) if need_a else None
+        db = torch.empty_like(b) if need_b else None
+        dw = torch.empty(2, dtype=torch.float32, device=b.device) if need_w else None
+        gacc = torch.empty(2, dtype=torch.float32, device=b.device) if need_w else None
+        rc = _C.lib().sihl_fuse_up2_bwd(_p(dout), _p(a), _p(b), _p(wr), _p(da), _p(db), _p(dw), _p(gacc), N, H, W, C,
+                                        _dt(b), _stream())
+        check(rc, "sihl_fuse_up2_bwd")
+        return da, db, dw
+
+
+class BlurFuseFn(torch.autograd.Function):
+    """out = w0 * blurpool_s2(a) + w1 * b + w2 * c, or plain blurpool_s2(a) when b is None  (NHWC)."""
+
+    @staticmethod
+    def forward(ctx, a, b, c, wraw):
+        a = a.detach().contiguous()
+        N, H, W, C = a.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        fused = b is not None
+        if fused:
+            b, c, wr = b.detach().contiguous(), c.detach().contiguous(), wraw.detach().float().contiguous()
+        else:
+            wr = None
+        out = torch.empty((N, Ho, Wo, C), dtype=a.dtype, device=a.device)
+        rc = _C.lib().sihl_blur_fuse(_p(a), _p(b), _p(c), _p(wr), _p(out), N, H, W, C, _dt(a), _stream())
+        check(rc, "sihl_blur_fuse")
+        ctx.fused = fused
+        ctx.save_for_backward(a, b, c, wr)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, b, c, wr = ctx.saved_tensors
+        dout = dout.contiguous()
+        N, H, W, C = a.shape
+        need_a, need_b, need_c, need_w = ctx.needs_input_grad
+        dev = a.device
+        da = torch.empty_like(a) if need_a else None
+        db = torch.empty_like(dout) if (ctx.fused and need_b) else None
+        dc = torch.empty_like(dout) if (ctx.fused and need_c) else None
+        dw = torch.empty(3, dtype=torch.float32, device=dev) if (ctx.fused and need_w) else None
+        gacc = torch.empty(3, dtype=torch.float32, device=dev) if dw is not None else None
+        rc = _C.lib().sihl_blur_fuse_bwd(_p(dout), _p(a), _p(b), _p(c), _p(wr), _p(da), _p(db), _p(dc), _p(dw),
+                                         _p(gacc), N, H, W, C, _dt(a), _stream())
+        check(rc, "sihl_blur_fuse_bwd")
+        return da, db, dc, dw
+
+
+class Up2Fn(torch.autograd.Function):
+    """Plain bilinear x2 upsample (align_corners=False), NHWC."""
+
+    @staticmethod
+    def forward(ctx, a):
+        a = a.detach().contiguous()
+        N, h, w, C = a.shape
+        out = torch.empty((N, 2 * h, 2 * w, C), dtype=a.dtype, device=a.device)
+        rc = _C.lib().sihl_fuse_up2(_p(a), None, None, _p(out), N, 2 * h, 2 * w, C, _dt(a), _stream())
+        check(rc, "sihl_fuse_up2")
+        ctx.shape = (N, h, w, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        N, h, w, C = ctx.shape
+        da = torch.empty((N, h, w, C), dtype=dout.dtype, device=dout.device)
+        rc = _C.lib().sihl_fuse_up2_bwd(_p(dout), None, None, None, _p(da), None, None, None, N, 2 * h, 2 * w, C,
+                                        _dt(dout), _stream())
+        check(rc, "sihl_fuse_up2_bwd")
+        return da
+
+
+class FuseSumFn(torch.autograd.Function):
+    """sum_i softmax(w)_i * x_i for 2 or 3 same-shaped tensors (stand-alone FastNormalizedFusion)."""
+
+    @staticmethod
+    def forward(ctx, wraw, *xs):
+        xs = [x.detach().contiguous() for x in xs]
+        wr = wraw.detach().float().contiguous()
+        n = len(xs)
+        out = torch.empty_like(xs[0])
+        rc = _C.lib().sihl_fuse_sum(_p(xs[0]), _p(xs[1]), _p(xs[2]) if n > 2 else None, _p(wr), _p(out),
+                                    out.numel(), n, _dt(out), _stream())
+        check(rc, "sihl_fuse_sum")
+        ctx.save_for_backward(wr, *xs)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        wr, *xs = ctx.saved_tensors
+        n = len(xs)
+        dout = dout.contiguous()
+        need = ctx.needs_input_grad
+        ds = [torch.empty_like(x) if need[1 + i] else None for i, x in enumerate(xs)]
+        dw = torch.empty(n, dtype=torch.float32, device=dout.device) if need[0] else None
+        gacc = torch.empty(3, dtype=torch.float32, device=dout.device) if need[0] else None
+        rc = _C.lib().sihl_fuse_sum_bwd(_p(dout), _p(xs[0]), _p(xs[1]), _p(xs[2]) if n > 2 else None, _p(wr),
+                                        _p(ds[0]), _p(ds[1]), _p(ds[2]) if n > 2 else None, _p(dw), _p(gacc),
+                                        dout.numel(), n, _dt(dout), _stream())
+        check(rc, "sihl_fuse_sum_bwd")
+        return (dw, *ds)
+
+
+def fuse_up2(a, b, wraw):
+    return FuseUp2Fn.apply(a, b, wraw)
+
+
+def up2(a):
+    return Up2Fn.apply(a)
+
+
+def fuse_sum(wraw, xs):
+    return FuseSumFn.apply(wraw, *xs)
+
+
+def blur_fuse(a, b=None, c=None, wraw=None):
+    return BlurFuseFn.apply(a, b, c, wraw)
+
+
+# ----------------------------------------------------------------------------- MLP pieces (rows x C)
+def _pad_rows(t: Tensor, mult: int) -> Tensor:
+    """Zero-pad dim 0 up to a multiple of ``mult`` (weights / biases of tiny output layers)."""
+    n = t.shape[0]
+    m = (n + mult - 1) // mult * mult
+    if m == n:
+        return t
+    out = t.new_zeros((m,) + tuple(t.shape[1:]))
+    out[:n] = t
+    return out
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x @ W^T + b over rows, as a 1x1 convolution on the matrix cores.  Output channels are
+    padded to the 16-byte vector width inside (Cout = 1 / 4 heads) and sliced back."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        xd = x.detach().contiguous()
+        rows, Cin = xd.shape
+        vec = 8 if xd.dtype == torch.bfloat16 else 4
+        Cout = weight.shape[0]
+        w = _pad_rows(weight.detach().to(xd.dtype), vec).contiguous()
+        b = _pad_rows(bias.detach().float(), vec).contiguous() if bias is not None else None
+        Cp = w.shape[0]
+        y, _ = conv2d_raw(xd.view(1, 1, rows, Cin), w.view(Cp, 1, 1, Cin), b)
+        ctx.save_for_backward(xd, w)
+        ctx.Cout, ctx.has_bias = Cout, bias is not None
+        y = y.view(rows, Cp)
+        return y if Cp == Cout else y[:, :Cout]
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        rows, Cin = x.shape
+        Cp, Cout = w.shape[0], ctx.Cout
+        if Cp != Cout:
+            dyp = dy.new_zeros((rows, Cp))
+            dyp[:, :Cout] = dy
+            dy = dyp
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = weight_for_dgrad(w.view(Cp, 1, 1, Cin), flip=False)  # [Cin][1][1][Cp]
+            dx, _ = conv2d_raw(dy.view(1, 1, rows, Cp), wt)
+            dx = dx.view(rows, Cin)
+        if ctx.needs_input_grad[1]:
+            dw = conv2d_wgrad_raw(x.view(1, 1, rows, Cin), dy.view(1, 1, rows, Cp), 1, 1, 1, 0, 1).view(Cp, Cin)[:Cout]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy)[:Cout]
+        return dx, dw, db
+
+
+class LayerNormActFn(torch.autograd.Function):
+    """y = act(LayerNorm(z) * gamma + beta) over rows."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, eps, act):
+        zd = z.detach().contiguous()
+        rows, C = zd.shape
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        y = torch.empty_like(zd)
+        mean = torch.empty(rows, dtype=torch.float32, device=zd.device)
+        rstd = torch.empty_like(mean)
+        rc = _C.lib().sihl_layernorm_act(_p(zd), _p(y), rows, C, _p(g), _p(b), eps, ACT[act], _p(mean), _p(rstd),
+                                         _dt(zd), _stream())
+        check(rc, "sihl_layernorm_act")
+        ctx.save_for_backward(zd, g, b, mean, rstd)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, g, b, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        rows, C = z.shape
+        lib = _C.lib()
+        ws = workspace(lib.sihl_layernorm_act_bwd_ws_bytes(rows, C), z.device)
+        dz = torch.empty_like(z)
+        dgamma = torch.empty(C, dtype=torch.float32, device=z.device)
+        dbeta = torch.empty_like(dgamma)
+        rc = lib.sihl_layernorm_act_bwd(_p(z), _p(dy), _p(dz), rows, C, _p(g), _p(b), _p(mean), _p(rstd),
+                                        ACT[ctx.act], _p(dgamma), _p(dbeta), _dt(z), _p(ws), ws.numel(), _stream())
+        check(rc, "sihl_layernorm_act_bwd")
+        return dz, dgamma, dbeta, None, None
+
+
+def linear(x, weight, bias):
+    return LinearFn.apply(x, weight, bias)
+
+
+def layernorm_act(z, gamma, beta, eps=1e-5, act="silu"):
+    return LayerNormActFn.apply(z, gamma, beta, eps, act)
+
+
+# ----------------------------------------------------------------------------- decode
+def topk_rows(x: Tensor, B: int, P: int, K: int, estride: int = 1):
+    vals = torch.empty((B, K), dtype=torch.float32, device=x.device)
+    idx = torch.empty((B, K), dtype=torch.int32, device=x.device)
+    rc = _C.lib().sihl_topk_rows(_p(x), B, P, K, estride, _p(vals), _p(idx), _dt(x), _stream())
+    check(rc, "sihl_topk_rows")
+    return vals, idx
+
+
+def gather_rows(src: Tensor, idx: Tensor) -> Tensor:
+    B, P, C = src.shape
+    K = idx.shape[1]
+    out = torch.empty((B, K, C), dtype=src.dtype, device=src.device)
+    rc = _C.lib().sihl_gather_rows(_p(src), _p(idx), _p(out), B, P, K, C, _dt(src), _stream())
+    check(rc, "sihl_gather_rows")
+    return out
+
+
+def _levels_arr(level_hw):
+    flat = [int(v) for hw in level_hw for v in hw]
+    return (ctypes.c_int * len(flat))(*flat)
+
+
+def od_decode(top_vals, top_idx, cls_logits, box_raw, level_hw, full_wh):
+    B, K = top_vals.shape
+    ncls = cls_logits.shape[-1]
+    dev = top_vals.device
+    scores = torch.empty((B, K), dtype=torch.float32, device=dev)
+    classes = torch.empty((B, K), dtype=torch.int64, device=dev)
+    boxes = torch.empty((B, K, 4), dtype=torch.float32, device=dev)
+    num = torch.empty((B,), dtype=torch.int64, device=dev)
+    cls_logits, box_raw = cls_logits.contiguous(), box_raw.contiguous()
+    rc = _C.lib().sihl_od_decode(_p(top_vals), _p(top_idx), _p(cls_logits), _p(box_raw), _levels_arr(level_hw),
+                                 len(level_hw), B, K, ncls, int(full_wh[0]), int(full_wh[1]), _p(scores),
+                                 _p(classes), _p(boxes), _p(num), _dt(cls_logits), _stream())
+    check(rc, "sihl_od_decode")
+    return num, scores, classes, boxes
+
+
+def od_anchors(level_hw, device):
+    P = sum(h * w for h, w in level_hw)
+    offsets = torch.empty((P, 4), dtype=torch.float32, device=device)
+    scales = torch.empty_like(offsets)
+    rc = _C.lib().sihl_od_anchors(_levels_arr(level_hw), len(level_hw), _p(offsets), _p(scales), _stream())
+    check(rc, "sihl_od_anchors")
+    return offsets, scales

@@ -1,0 +1,177 @@
+"""GPU: each HIP kernel against a plain fp32 PyTorch CPU computation of the same op (through the C-ABI)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+DTYPES = [(torch.float32, 2e-5, 2e-5), (torch.bfloat16, 3e-2, 3e-2)]
+
+
+def _ops():
+    from sihl_amd import ops
+    return ops
+
+
+def _close(got, want, rtol, atol, name=""):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    scale = max(1.0, float(want.abs().max()))
+    torch.testing.assert_close(got, want, rtol=rtol, atol=atol * scale, msg=lambda s: f"{name}: {s}")
+
+
+CONV_SHAPES = [
+    # N, H, W, Cin, Cout, K, stride, pad
+    (2, 12, 16, 32, 32, 3, 1, 1),
+    (2, 8, 8, 64, 256, 3, 1, 1),
+    (3, 8, 8, 64, 32, 1, 1, 0),
+    (1, 4, 4, 256, 256, 3, 1, 1),
+    (2, 1, 1, 32, 32, 3, 1, 1),
+    (2, 16, 16, 96, 160, 3, 1, 1),   # ragged channel chunks / Cout tiles
+    (2, 16, 16, 32, 32, 3, 2, 1),    # stride 2 (FPN extra levels)
+    (1, 1, 300, 256, 8, 1, 1, 0),    # linear head as 1x1 over rows
+    (4, 64, 64, 256, 256, 3, 1, 1),  # a real L3-like tile count
+]
+
+
+@pytest.mark.parametrize("dtype,rtol,atol", DTYPES)
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv_fwd_wgrad_dgrad(shape, dtype, rtol, atol):
+    ops = _ops()
+    N, H, W, Cin, Cout, K, s, p = shape
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    xq, wq = x.to(dtype).float(), w.to(dtype).float()
+    ref = F.conv2d(xq, wq, b, stride=s, padding=p)
+    xd = x.to(DEV, dtype).permute(0, 2, 3, 1).contiguous()
+    wd = w.to(DEV, dtype).permute(0, 2, 3, 1).contiguous()
+    y, _ = ops.conv2d_raw(xd, wd, b.to(DEV), s, p, 1)
+    _close(y.permute(0, 3, 1, 2), ref, rtol, atol, "fwd")
+    # relu + post-affine + stats
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    y2, stats = ops.conv2d_raw(xd, wd, None, s, p, 1, act="relu", post=(sc.to(DEV), sh.to(DEV)), stats_mode=2)
+    r = F.relu(F.conv2d(xq, wq, None, stride=s, padding=p))
+    _close(y2.permute(0, 3, 1, 2), r * sc[None, :, None, None] + sh[None, :, None, None], rtol, atol, "epilogue")
+    tot = stats.sum(0).cpu()
+    _close(tot[0], r.sum((0, 2, 3)), rtol, atol * 4, "stats.sum")
+    _close(tot[1], (r * r).sum((0, 2, 3)), rtol, atol * 4, "stats.sumsq")
+    # wgrad
+    dy = torch.randn(ref.shape, generator=g)
+    dyq = dy.to(dtype).float()
+    dyd = dy.to(DEV, dtype).permute(0, 2, 3, 1).contiguous()
+    xr, wr = xq.clone().requires_grad_(True), wq.clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, stride=s, padding=p).backward(dyq)
+    dw = ops.conv2d_wgrad_raw(xd, dyd, K, K, s, p, 1)
+    _close(dw.permute(0, 3, 1, 2), wr.grad, rtol, atol, "wgrad")
+    if s == 1:
+        wt = ops.weight_for_dgrad(wd, flip=True)
+        dx, _ = ops.conv2d_raw(dyd, wt, None, 1, K - 1 - p, 1)
+        _close(dx.permute(0, 3, 1, 2), xr.grad, rtol, atol, "dgrad")
+
+
+@pytest.mark.parametrize("dtype,rtol,atol", DTYPES)
+def test_fuse_up2_and_blur(dtype, rtol, atol):
+    ops = _ops()
+    g = torch.Generator().manual_seed(1)
+    for (N, C, h, w) in [(2, 32, 4, 6), (2, 32, 1, 1), (1, 64, 8, 8)]:
+        a = torch.randn(N, C, h, w, generator=g).to(dtype).float().requires_grad_(True)
+        b = torch.randn(N, C, 2 * h, 2 * w, generator=g).to(dtype).float().requires_grad_(True)
+        wr = torch.randn(2, generator=g).requires_grad_(True)
+        sm = wr.softmax(0)
+        ref = sm[0] * F.interpolate(a, scale_factor=2, mode="bilinear") + sm[1] * b
+        cot = torch.randn(ref.shape, generator=g).to(dtype).float()
+        ref.backward(cot)
+        ad = a.detach().to(DEV, dtype).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+        bd = b.detach().to(DEV, dtype).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+        wd = wr.detach().to(DEV).requires_grad_(True)
+        out = ops.fuse_up2(ad, bd, wd)
+        out.backward(cot.to(DEV, dtype).permute(0, 2, 3, 1).contiguous())
+        _close(out.permute(0, 3, 1, 2), ref, rtol, atol, "up2 fwd")
+        _close(ad.grad.permute(0, 3, 1, 2), a.grad, rtol, atol, "up2 da")
+        _close(bd.grad.permute(0, 3, 1, 2), b.grad, rtol, atol, "up2 db")
+        _close(wd.grad, wr.grad, rtol * 5, atol * 5, "up2 dw")
+    k = torch.tensor([0.25, 0.5, 0.25])
+    k2 = torch.outer(k, k)
+    for (N, C, H, W) in [(2, 32, 8, 12), (2, 32, 2, 2), (1, 64, 4, 4), (1, 32, 6, 10)]:
+        a = torch.randn(N, C, H, W, generator=g).to(dtype).float().requires_grad_(True)
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        b = torch.randn(N, C, Ho, Wo, generator=g).to(dtype).float().requires_grad_(True)
+        c = torch.randn(N, C, Ho, Wo, generator=g).to(dtype).float().requires_grad_(True)
+        wr = torch.randn(3, generator=g).requires_grad_(True)
+        sm = wr.softmax(0)
+        blur = F.conv2d(F.pad(a, [1, 1, 1, 1], mode="reflect"), k2[None, None].repeat(C, 1, 1, 1), stride=2, groups=C)
+        ref = sm[0] * blur + sm[1] * b + sm[2] * c
+        cot = torch.randn(ref.shape, generator=g).to(dtype).float()
+        ref.backward(cot)
+        mk = lambda t: t.detach().to(DEV, dtype).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+        ad, bd, cd = mk(a), mk(b), mk(c)
+        wd = wr.detach().to(DEV).requires_grad_(True)
+        out = ops.blur_fuse(ad, bd, cd, wd)
+        out.backward(cot.to(DEV, dtype).permute(0, 2, 3, 1).contiguous())
+        _close(out.permute(0, 3, 1, 2), ref, rtol, atol, "blur fwd")
+        _close(ad.grad.permute(0, 3, 1, 2), a.grad, rtol, atol, "blur da")
+        _close(bd.grad.permute(0, 3, 1, 2), b.grad, rtol, atol, "blur db")
+        _close(cd.grad.permute(0, 3, 1, 2), c.grad, rtol, atol, "blur dc")
+        _close(wd.grad, wr.grad, rtol * 5, atol * 5, "blur dw")
+
+
+@pytest.mark.parametrize("dtype,rtol,atol", DTYPES)
+def test_linear_layernorm(dtype, rtol, atol):
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    for rows, cin, cout in [(300, 256, 256), (77, 32, 1), (1000, 256, 80), (50, 32, 4)]:
+        x = torch.randn(rows, cin, generator=g).to(dtype).float().requires_grad_(True)
+        w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).requires_grad_(True)
+        b = torch.randn(cout, generator=g).requires_grad_(True)
+        ref = F.linear(x, w.to(dtype).float(), b)
+        cot = torch.randn(ref.shape, generator=g).to(dtype).float()
+        ref.backward(cot)
+        xd = x.detach().to(DEV, dtype).requires_grad_(True)
+        wd, bd = w.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+        y = ops.linear(xd, wd, bd)
+        y.backward(cot.to(DEV, dtype))
+        _close(y, ref, rtol, atol, "linear fwd")
+        _close(xd.grad, x.grad, rtol, atol, "linear dx")
+        _close(wd.grad, w.grad, rtol, atol, "linear dw")
+        _close(bd.grad, b.grad, rtol, atol, "linear db")
+    for rows, C in [(300, 256), (33, 32), (1000, 64)]:
+        z = torch.randn(rows, C, generator=g).to(dtype).float().requires_grad_(True)
+        ga = (1 + 0.3 * torch.randn(C, generator=g)).requires_grad_(True)
+        be = (0.3 * torch.randn(C, generator=g)).requires_grad_(True)
+        ref = F.silu(F.layer_norm(z, (C,), ga, be))
+        cot = torch.randn(ref.shape, generator=g).to(dtype).float()
+        ref.backward(cot)
+        zd = z.detach().to(DEV, dtype).requires_grad_(True)
+        gd, bd = ga.detach().to(DEV).requires_grad_(True), be.detach().to(DEV).requires_grad_(True)
+        y = ops.layernorm_act(zd, gd, bd)
+        y.backward(cot.to(DEV, dtype))
+        _close(y, ref, rtol, atol, "ln fwd")
+        _close(zd.grad, z.grad, rtol, atol, "ln dz")
+        _close(gd.grad, ga.grad, rtol, atol, "ln dgamma")
+        _close(bd.grad, be.grad, rtol, atol, "ln dbeta")
+
+
+def test_topk_gather_decode():
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    B, P, K, C = 3, 341, 100, 32
+    logits = torch.randn(B, P, generator=g)
+    v, i = logits.topk(K, dim=1)
+    vd, idx = ops.topk_rows(logits.to(DEV), B, P, K)
+    assert torch.equal(idx.cpu().long(), i)
+    torch.testing.assert_close(vd.cpu(), v)
+    # padded / strided logits as produced by the linear head
+    padded = torch.zeros(B * P, 4)
+    padded[:, 0] = logits.reshape(-1)
+    vd2, idx2 = ops.topk_rows(padded.to(DEV), B, P, K, estride=4)
+    assert torch.equal(idx2.cpu().long(), i)
+    feats = torch.randn(B, P, C, generator=g)
+    sel = ops.gather_rows(feats.to(DEV), idx)
+    torch.testing.assert_close(sel.cpu(), feats[torch.arange(B)[:, None], i])
+    # big P (full-size pyramid)
+    logits = torch.randn(2, 5456, generator=g)
+    v, i = logits.topk(K, dim=1)
+    vd, idx = ops.topk_rows(logits.to(DEV), 2, 5456, K)
+    assert torch.equal(idx.cpu().long(), i)
