@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec, forward+backward (+ gradient all-reduce + clip + AdamW step),
+ResNet50 + BiFPN(3-7, 256 ch, 3 layers) + ObjectDetection(80 classes), bs=32 per GPU, 3x512x512, bf16,
+synthetic data (BASELINE.json configs[2] / SURVEY §8(d)).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+One process per GPU; each rank owns its own 32-image shard (weak scaling) and gradients are averaged with
+bucketed RCCL all-reduces overlapped with backward.  Rank 0 prints ONE JSON line.  Besides the contract's
+fields it carries
+  roofline     - the dominant kernel (bf16 implicit-GEMM conv on the matrix cores): algorithmic flops per launch
+                 over its average launch duration, timed with HIP events on the launch stream DURING the timed
+                 steps, against the dense bf16 MFMA peak;
+  cpu_baseline - the CPU oracle (fp32 PyTorch restatement of the reference) timed on this box's host cores on a
+                 bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "images/sec fwd+bwd, ResNet50+BiFPN+det-head bs=32 512², 1/2/4/8 MI355X"
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def synthetic_batch(batch, size, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    images = torch.rand(batch, 3, size, size, generator=g)
+    gt = torch.Generator().manual_seed(seed + 1)
+    classes, boxes = [], []
+    for b in range(batch):
+        n = int(torch.randint(0, 9, (1,), generator=gt))
+        if b == 1:
+            n = 0  # always keep an image without objects (tests/heads/test_object_detection.py:42)
+        xy = torch.rand(n, 2, generator=gt) * (size * 0.75)
+        wh = 16 + torch.rand(n, 2, generator=gt) * (size * 0.25 - 16)
+        boxes.append(torch.cat([xy, xy + wh], dim=1).to(device))
+        classes.append(torch.randint(0, 80, (n,), generator=gt).to(device))
+    images = images.to(device).contiguous(memory_format=torch.channels_last)
+    return images, [{"classes": classes, "boxes": boxes}]
+
+
+def build_model(ns, device):
+    torch.manual_seed(0)
+    backbone = ns.ResNetBackbone("resnet50", top_level=5)
+    neck = ns.BiFPN(backbone.out_channels, 256, 3, 7, num_layers=3)
+    head = ns.ObjectDetection(neck.out_channels, num_classes=80, bottom_level=3, top_level=7, num_channels=256)
+    model = ns.SihlModel(backbone, neck, [head])
+    return model.to(device).to(memory_format=torch.channels_last)
+
+
+def usable_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def cpu_baseline(sample_batch, size, iters=2):
+    """The oracle (CPU port of the reference path) on a bounded sample: same model, same step, fp32."""
+    import types
+
+    import oracle
+    from sihl_amd.train import Trainer
+
+    ns = types.SimpleNamespace(ResNetBackbone=oracle.ResNetBackbone, BiFPN=oracle.BiFPN,
+                               ObjectDetection=oracle.ObjectDetection, SihlModel=oracle.SihlModel)
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    model = build_model(ns, "cpu")
+    trainer = Trainer(model, lr=1e-4, weight_decay=1e-4, backbone_lr_factor=0.1)
+    images, targets = synthetic_batch(sample_batch, size, "cpu", seed=0)
+    trainer.step(images, targets)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        trainer.step(images, targets)
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": sample_batch / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (CPU fp32 restatement) fwd+bwd+step, bs={sample_batch} of the same {size}x{size} "
+                      f"workload, mean of {iters} steps after 1 warm-up ({dt:.2f} s/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import sihl_amd
+    from sihl_amd import _C
+    from sihl_amd.train import Trainer
+
+    import types
+
+    hip_ns = types.SimpleNamespace(ResNetBackbone=sihl_amd.ResNetBackbone, BiFPN=sihl_amd.layers.BiFPN,
+                                   ObjectDetection=sihl_amd.heads.ObjectDetection, SihlModel=sihl_amd.SihlModel)
+    model = build_model(hip_ns, device)
+    amp = torch.bfloat16 if args.dtype == "bf16" else None
+    trainer = Trainer(model, lr=1e-4, weight_decay=1e-4, backbone_lr_factor=0.1, grad_clip_norm=0.1,
+                      autocast_dtype=amp)
+    images, targets = synthetic_batch(args.batch, args.size, device, seed=rank)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(images, targets)
+    lib = _C.lib()
+    sync()
+    lib.sihl_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = trainer.step(images, targets)
+    sync()
+    dt = time.perf_counter() - t0
+    lib.sihl_profile_enable(0)
+
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    # roofline of the dominant kernel: matrix-core conv (forward / dgrad / linear launches)
+    dt_code = _C.BF16 if args.dtype == "bf16" else _C.F32
+    n, ms, fl, by = ctypes.c_long(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    lib.sihl_profile_collect(0, dt_code, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by))
+    nw, msw, flw, byw = ctypes.c_long(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    lib.sihl_profile_collect(1, dt_code, ctypes.byref(nw), ctypes.byref(msw), ctypes.byref(flw), ctypes.byref(byw))
+    peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+    roofline = None
+    if n.value:
+        achieved = fl.value / (ms.value * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (NHWC implicit-GEMM conv: fwd / dgrad / linear)",
+                    "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                    "launches_per_step": n.value / args.steps, "avg_launch_us": ms.value * 1e3 / n.value,
+                    "avg_gflop_per_launch": fl.value / n.value / 1e9,
+                    "kernel_ms_per_step": ms.value / args.steps,
+                    "wgrad": {"achieved": (flw.value / (msw.value * 1e-3) / 1e12) if nw.value else None,
+                              "launches_per_step": nw.value / args.steps,
+                              "kernel_ms_per_step": msw.value / args.steps}}
+
+    if rank == 0:
+        out = {
+            "metric": METRIC, "value": args.batch * world * args.steps / dt, "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "ResNet50 + BiFPN(3-7,256ch,3 layers) + ObjectDetection(80 cls) training step: "
+                                   "fwd + bwd + grad all-reduce + clip(0.1) + AdamW, random-init weights",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                       "image": f"3x{args.size}x{args.size}", "parallelism": f"dp{world}",
+                       "final_loss": float(loss)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.size)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

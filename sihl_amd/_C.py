@@ -31,6 +31,10 @@ SIGNATURES = {
     "sihl_norm_act_bwd": (I, [P, P, P, L, I, P, P, P, P, P, P, I, I, I, I, P, L, P]),
     "sihl_fuse_up2": (I, [P, P, P, P, I, I, I, I, I, P]),
     "sihl_fuse_up2_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "sihl_nearest_up2_add": (I, [P, P, P, I, I, I, I, I, P]),
+    "sihl_nearest_up2_add_bwd": (I, [P, P, I, I, I, I, I, P]),
+    "sihl_resize_bilinear": (I, [P, P, P, I, I, I, I, I, I, I, P]),
+    "sihl_resize_bilinear_bwd": (I, [P, P, I, I, I, I, I, I, I, P]),
     "sihl_fuse_sum": (I, [P, P, P, P, P, L, I, I, P]),
     "sihl_fuse_sum_bwd": (I, [P, P, P, P, P, P, P, P, P, P, L, I, I, P]),
     "sihl_blur_fuse": (I, [P, P, P, P, P, I, I, I, I, I, P]),
@@ -45,6 +49,8 @@ SIGNATURES = {
     "sihl_gather_rows": (I, [P, P, P, I, I, I, I, I, P]),
     "sihl_od_decode": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, I, P]),
     "sihl_od_anchors": (I, [P, I, P, P, P]),
+    "sihl_profile_enable": (I, [I]),
+    "sihl_profile_collect": (I, [I, I, P, P, P, P]),
 }
 
 _lib = None

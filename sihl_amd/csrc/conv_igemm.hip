@@ -18,6 +18,7 @@
 // transposed through LDS and written with 16-byte row-contiguous stores; per-channel (sum, sumsq)
 // partials for BatchNorm batch statistics go to a workspace row per M-tile (deterministic, no atomics).
 #include "common.h"
+#include "profile.h"
 
 namespace {
 
@@ -255,7 +256,11 @@ int launch(const ConvParams& p0, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
+  const double flops = 2.0 * p.M * (double)p.Cout * p.KH * p.KW * p.Cin;
+  const double bytes = ((double)p.N * p.H * p.W * p.Cin + (double)p.M * p.Cout + (double)p.Cout * p.KH * p.KW * p.Cin) * sizeof(T);
+  sihl_prof_begin(SIHL_PROF_CONV, sizeof(T) == 2 ? SIHL_BF16 : SIHL_F32, flops, bytes, stream);
   hipLaunchKernelGGL(kern, dim3(p.gridM * p.gridN), dim3(256), LDS, stream, p);
+  sihl_prof_end(stream);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
 }

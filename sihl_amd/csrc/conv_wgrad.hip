@@ -11,6 +11,7 @@
 // Workgroup = 128 co x 128 ci of one tap over one K-split of the pixels; fp32 partial tiles go to
 // a workspace [split][Cout][taps][Cin] and sihl_wgrad_reduce sums the splits (deterministic).
 #include "common.h"
+#include "profile.h"
 
 namespace {
 
@@ -204,7 +205,11 @@ int launch(WgradParams p, hipStream_t stream) {
     attr_set = true;
   }
   const int grid = p.KH * p.KW * p.tiles_co * p.tiles_ci * p.splits;
+  const double flops = 2.0 * p.M * (double)p.Cout * p.KH * p.KW * p.Cin;
+  const double bytes = ((double)p.N * p.H * p.W * p.Cin + (double)p.M * p.Cout) * sizeof(T) + (double)p.Cout * p.KH * p.KW * p.Cin * 4.0;
+  sihl_prof_begin(SIHL_PROF_WGRAD, sizeof(T) == 2 ? SIHL_BF16 : SIHL_F32, flops, bytes, stream);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, stream, p);
+  sihl_prof_end(stream);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
 }

@@ -274,6 +274,139 @@ __global__ void up2_adjoint_kernel(const T* __restrict__ dout, const float* __re
   }
 }
 
+
+// ------------------------------------------------------------------ nearest x2 upsample + add (FPN top-down, fpn.py:43-48)
+template <typename T>
+__global__ void nearest_up2_add_kernel(const T* __restrict__ lo, const T* __restrict__ skip, T* __restrict__ out,
+                                       int N, int H, int W, int C) {
+  constexpr int V = 16 / sizeof(T);
+  const int cvec = C / V, h2 = H / 2, w2 = W / 2;
+  const long nvec = (long)N * H * W * cvec;
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+    const int cv = (int)(i % cvec);
+    long pix = i / cvec;
+    const int x = (int)(pix % W); pix /= W;
+    const int y = (int)(pix % H);
+    const int n = (int)(pix / H);
+    float a[V], b[V];
+    ldv(lo + ((((long)n * h2 + y / 2) * w2 + x / 2) * cvec + cv) * V, a);
+    ldv(skip + i * V, b);
+#pragma unroll
+    for (int e = 0; e < V; ++e) a[e] += b[e];
+    stv(out + i * V, a);
+  }
+}
+
+// d_lo[i][j] = sum of the 2x2 block of dout
+template <typename T>
+__global__ void nearest_up2_adjoint_kernel(const T* __restrict__ dout, T* __restrict__ dlo, int N, int H, int W,
+                                           int C) {
+  constexpr int V = 16 / sizeof(T);
+  const int cvec = C / V, h2 = H / 2, w2 = W / 2;
+  const long nvec = (long)N * h2 * w2 * cvec;
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+    const int cv = (int)(i % cvec);
+    long pix = i / cvec;
+    const int x = (int)(pix % w2); pix /= w2;
+    const int y = (int)(pix % h2);
+    const int n = (int)(pix / h2);
+    float acc[V], d[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        ldv(dout + ((((long)n * H + 2 * y + dy) * W + 2 * x + dx) * cvec + cv) * V, d);
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] += d[e];
+      }
+    stv(dlo + i * V, acc);
+  }
+}
+
+// ------------------------------------------------------------------ general bilinear resize, align_corners=False
+__device__ __forceinline__ Lerp resize_src(int dst, int in_size, float scale) {
+  float src = scale * (dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  Lerp r;
+  r.i0 = min((int)src, in_size - 1);
+  r.i1 = min(r.i0 + 1, in_size - 1);
+  r.l1 = src - r.i0;
+  r.l0 = 1.f - r.l1;
+  return r;
+}
+
+// out[N][Ho][Wo][C] = resize(a[N][H][W][C]) (+ add)
+template <typename T>
+__global__ void resize_bilinear_kernel(const T* __restrict__ a, const T* __restrict__ add, T* __restrict__ out, int N,
+                                       int H, int W, int Ho, int Wo, int C) {
+  constexpr int V = 16 / sizeof(T);
+  const int cvec = C / V;
+  const long nvec = (long)N * Ho * Wo * cvec;
+  const float sy = (float)H / Ho, sx = (float)W / Wo;
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+    const int cv = (int)(i % cvec);
+    long pix = i / cvec;
+    const int x = (int)(pix % Wo); pix /= Wo;
+    const int y = (int)(pix % Ho);
+    const int n = (int)(pix / Ho);
+    const Lerp ly = resize_src(y, H, sy), lx = resize_src(x, W, sx);
+    const T* an = a + (long)n * H * W * C + cv * V;
+    float f00[V], f01[V], f10[V], f11[V], o[V];
+    ldv(an + ((long)ly.i0 * W + lx.i0) * C, f00);
+    ldv(an + ((long)ly.i0 * W + lx.i1) * C, f01);
+    ldv(an + ((long)ly.i1 * W + lx.i0) * C, f10);
+    ldv(an + ((long)ly.i1 * W + lx.i1) * C, f11);
+    if (add) ldv(add + i * V, o);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float v = ly.l0 * (lx.l0 * f00[e] + lx.l1 * f01[e]) + ly.l1 * (lx.l0 * f10[e] + lx.l1 * f11[e]);
+      o[e] = add ? o[e] + v : v;
+    }
+    stv(out + i * V, o);
+  }
+}
+
+// da[y][x] = sum over the output pixels whose 2x2 footprint touches (y, x)
+template <typename T>
+__global__ void resize_bilinear_adjoint_kernel(const T* __restrict__ dout, T* __restrict__ da, int N, int H, int W,
+                                               int Ho, int Wo, int C) {
+  constexpr int V = 16 / sizeof(T);
+  const int cvec = C / V;
+  const long nvec = (long)N * H * W * cvec;
+  const float sy = (float)H / Ho, sx = (float)W / Wo;
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+    const int cv = (int)(i % cvec);
+    long pix = i / cvec;
+    const int x = (int)(pix % W); pix /= W;
+    const int y = (int)(pix % H);
+    const int n = (int)(pix / H);
+    // conservative candidate ranges; exact membership is re-tested with the forward formula
+    const int oy_lo = max(0, (int)floorf((y - 0.5f) / sy - 0.5f) - 1), oy_hi = min(Ho - 1, (int)ceilf((y + 1.5f) / sy - 0.5f) + 1);
+    const int ox_lo = max(0, (int)floorf((x - 0.5f) / sx - 0.5f) - 1), ox_hi = min(Wo - 1, (int)ceilf((x + 1.5f) / sx - 0.5f) + 1);
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+    const T* dn = dout + (long)n * Ho * Wo * C + cv * V;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      const Lerp ly = resize_src(oy, H, sy);
+      const float wy = (ly.i0 == y ? ly.l0 : 0.f) + (ly.i1 == y ? ly.l1 : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        const Lerp lx = resize_src(ox, W, sx);
+        const float wx = (lx.i0 == x ? lx.l0 : 0.f) + (lx.i1 == x ? lx.l1 : 0.f);
+        if (wx == 0.f) continue;
+        float d[V];
+        ldv(dn + ((long)oy * Wo + ox) * C, d);
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] += wy * wx * d[e];
+      }
+    }
+    stv(da + i * V, acc);
+  }
+}
+
 // ------------------------------------------------------------------ blur (reflect, [1,2,1]^2/16, stride 2) + fuse
 // out = w0*blur(a) + w1*b + w2*c       a: [N][H][W][C]; b,c,out: [N][Ho][Wo][C]; b==null -> out = blur(a)
 template <typename T>
@@ -824,6 +957,60 @@ int sihl_fuse_up2_bwd(const void* dout, const void* a, const void* b, const floa
   return SIHL_OK;
 }
 
+
+// out[N][H][W][C] = nearest_x2(lo[N][H/2][W/2][C]) + skip
+int sihl_nearest_up2_add(const void* lo, const void* skip, void* out, int N, int H, int W, int C, int dtype,
+                         hipStream_t stream) {
+  if (!lo || !skip || !out || N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return SIHL_EARG;
+  DISPATCH_DTYPE(dtype, {
+    constexpr int V = 16 / sizeof(T);
+    if (C % V) return SIHL_EARG;
+    hipLaunchKernelGGL(nearest_up2_add_kernel<T>, dim3(grid_for((long)N * H * W * (C / V))), dim3(TPB), 0, stream,
+                       (const T*)lo, (const T*)skip, (T*)out, N, H, W, C);
+  });
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+// dlo[N][H/2][W/2][C] = 2x2 block sums of dout[N][H][W][C]   (the skip gradient is dout itself)
+int sihl_nearest_up2_add_bwd(const void* dout, void* dlo, int N, int H, int W, int C, int dtype, hipStream_t stream) {
+  if (!dout || !dlo || N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return SIHL_EARG;
+  DISPATCH_DTYPE(dtype, {
+    constexpr int V = 16 / sizeof(T);
+    if (C % V) return SIHL_EARG;
+    hipLaunchKernelGGL(nearest_up2_adjoint_kernel<T>, dim3(grid_for((long)N * (H / 2) * (W / 2) * (C / V))), dim3(TPB),
+                       0, stream, (const T*)dout, (T*)dlo, N, H, W, C);
+  });
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+// out[N][Ho][Wo][C] = bilinear_resize(a[N][H][W][C]) (+ add if non-null), align_corners=False
+int sihl_resize_bilinear(const void* a, const void* add, void* out, int N, int H, int W, int Ho, int Wo, int C,
+                         int dtype, hipStream_t stream) {
+  if (!a || !out || N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return SIHL_EARG;
+  DISPATCH_DTYPE(dtype, {
+    constexpr int V = 16 / sizeof(T);
+    if (C % V) return SIHL_EARG;
+    hipLaunchKernelGGL(resize_bilinear_kernel<T>, dim3(grid_for((long)N * Ho * Wo * (C / V))), dim3(TPB), 0, stream,
+                       (const T*)a, (const T*)add, (T*)out, N, H, W, Ho, Wo, C);
+  });
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+int sihl_resize_bilinear_bwd(const void* dout, void* da, int N, int H, int W, int Ho, int Wo, int C, int dtype,
+                             hipStream_t stream) {
+  if (!dout || !da || N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return SIHL_EARG;
+  DISPATCH_DTYPE(dtype, {
+    constexpr int V = 16 / sizeof(T);
+    if (C % V) return SIHL_EARG;
+    hipLaunchKernelGGL(resize_bilinear_adjoint_kernel<T>, dim3(grid_for((long)N * H * W * (C / V))), dim3(TPB), 0,
+                       stream, (const T*)dout, (T*)da, N, H, W, Ho, Wo, C);
+  });
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
 
 // out = sum_i softmax(wraw)_i * x_i over n (2 or 3) same-shaped tensors of `numel` elements
 int sihl_fuse_sum(const void* x0, const void* x1, const void* x2, const float* wraw, void* out, long numel, int n,

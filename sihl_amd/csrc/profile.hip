@@ -1,0 +1,66 @@
+#include "profile.h"
+#include <vector>
+#include <mutex>
+
+namespace {
+struct Rec { hipEvent_t a, b; int slot, dtype; double flops, bytes; };
+bool g_on = false;
+std::vector<Rec> g_recs;
+std::mutex g_mu;
+Rec g_cur;
+bool g_open = false;
+}  // namespace
+
+void sihl_prof_begin(int slot, int dtype, double flops, double bytes, hipStream_t stream) {
+  if (!g_on) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_cur.slot = slot; g_cur.dtype = dtype; g_cur.flops = flops; g_cur.bytes = bytes;
+  if (hipEventCreate(&g_cur.a) != hipSuccess || hipEventCreate(&g_cur.b) != hipSuccess) return;
+  (void)hipEventRecord(g_cur.a, stream);
+  g_open = true;
+}
+
+void sihl_prof_end(hipStream_t stream) {
+  if (!g_on || !g_open) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  (void)hipEventRecord(g_cur.b, stream);
+  g_recs.push_back(g_cur);
+  g_open = false;
+}
+
+extern "C" {
+
+// Turn per-launch event timing on/off; turning it on clears earlier records.
+int sihl_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (on) {
+    for (auto& r : g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_recs.clear();
+  }
+  g_on = on != 0;
+  return 0;
+}
+
+// Sum the records of (slot, dtype): launches, total milliseconds, total algorithmic flops and bytes.
+// Synchronises on the recorded events.
+int sihl_profile_collect(int slot, int dtype, long* launches, double* total_ms, double* total_flops,
+                         double* total_bytes) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  long n = 0; double ms = 0, fl = 0, by = 0;
+  for (auto& r : g_recs) {
+    if (r.slot != slot || r.dtype != dtype) continue;
+    hipError_t e = hipEventSynchronize(r.b);
+    if (e != hipSuccess) return (int)e;
+    float t = 0.f;
+    e = hipEventElapsedTime(&t, r.a, r.b);
+    if (e != hipSuccess) return (int)e;
+    ++n; ms += t; fl += r.flops; by += r.bytes;
+  }
+  if (launches) *launches = n;
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (total_bytes) *total_bytes = by;
+  return 0;
+}
+
+}  // extern "C"

@@ -186,11 +186,10 @@ class ConvBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, cfg):
-        stride, pad, dil, act, order, has_norm, training, eps, momentum = cfg
+        stride, pad, dil, act, order, has_norm, training, eps, momentum, need_grad = cfg
         xd = x.detach()
         w = weight_khwc(weight, xd.dtype)
         KH, KW = w.shape[1], w.shape[2]
-        need_grad = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)
         ctx.cfg, ctx.has_norm, ctx.kshape = cfg, has_norm, (KH, KW)
         ctx.has_bias = bias is not None
         if not has_norm:
@@ -236,7 +235,7 @@ class ConvBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        stride, pad, dil, act, order, has_norm, training, eps, momentum = ctx.cfg
+        stride, pad, dil, act, order, has_norm, training, eps, momentum, _ = ctx.cfg
         KH, KW = ctx.kshape
         dy = dy.contiguous()
         dgamma = dbeta = None
@@ -264,7 +263,10 @@ class ConvBlockFn(torch.autograd.Function):
 def conv_block(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, *, stride=1, pad=0, dil=1, act=None,
                order="act_norm", training=False, eps=1e-5, momentum=0.1):
     has_norm = running_mean is not None
-    cfg = (stride, pad, dil, act, order, has_norm, training, eps, momentum)
+    # autograd.Function.forward always runs with grad mode off, so decide here whether a backward can follow
+    need_grad = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in (x_nhwc, weight, bias, gamma, beta))
+    cfg = (stride, pad, dil, act, order, has_norm, training, eps, momentum, need_grad)
     return ConvBlockFn.apply(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, cfg)
 
 
@@ -389,6 +391,66 @@ class FuseSumFn(torch.autograd.Function):
                                         dout.numel(), n, _dt(dout), _stream())
         check(rc, "sihl_fuse_sum_bwd")
         return (dw, *ds)
+
+
+class NearestUp2AddFn(torch.autograd.Function):
+    """out = nearest_x2(lo) + skip (FPN top-down merge), NHWC."""
+
+    @staticmethod
+    def forward(ctx, lo, skip):
+        lo, skip = lo.detach().contiguous(), skip.detach().contiguous()
+        N, H, W, C = skip.shape
+        out = torch.empty_like(skip)
+        rc = _C.lib().sihl_nearest_up2_add(_p(lo), _p(skip), _p(out), N, H, W, C, _dt(skip), _stream())
+        check(rc, "sihl_nearest_up2_add")
+        ctx.lo_shape = tuple(lo.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        N, H, W, C = dout.shape
+        dlo = None
+        if ctx.needs_input_grad[0]:
+            dlo = torch.empty(ctx.lo_shape, dtype=dout.dtype, device=dout.device)
+            rc = _C.lib().sihl_nearest_up2_add_bwd(_p(dout), _p(dlo), N, H, W, C, _dt(dout), _stream())
+            check(rc, "sihl_nearest_up2_add_bwd")
+        return dlo, dout if ctx.needs_input_grad[1] else None
+
+
+class ResizeBilinearFn(torch.autograd.Function):
+    """out = bilinear_resize(a, size) (+ add), align_corners=False, NHWC."""
+
+    @staticmethod
+    def forward(ctx, a, add, size):
+        a = a.detach().contiguous()
+        N, H, W, C = a.shape
+        Ho, Wo = size
+        addc = add.detach().contiguous() if add is not None else None
+        out = torch.empty((N, Ho, Wo, C), dtype=a.dtype, device=a.device)
+        rc = _C.lib().sihl_resize_bilinear(_p(a), _p(addc), _p(out), N, H, W, Ho, Wo, C, _dt(a), _stream())
+        check(rc, "sihl_resize_bilinear")
+        ctx.geom = (N, H, W, Ho, Wo, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        N, H, W, Ho, Wo, C = ctx.geom
+        da = None
+        if ctx.needs_input_grad[0]:
+            da = torch.empty((N, H, W, C), dtype=dout.dtype, device=dout.device)
+            rc = _C.lib().sihl_resize_bilinear_bwd(_p(dout), _p(da), N, H, W, Ho, Wo, C, _dt(dout), _stream())
+            check(rc, "sihl_resize_bilinear_bwd")
+        return da, dout if ctx.needs_input_grad[1] else None, None
+
+
+def nearest_up2_add(lo, skip):
+    return NearestUp2AddFn.apply(lo, skip)
+
+
+def resize_bilinear(a, size, add=None):
+    return ResizeBilinearFn.apply(a, add, tuple(size))
 
 
 def fuse_up2(a, b, wraw):

@@ -1,0 +1,164 @@
+"""Minimal data-parallel training loop for the hot path (one process per GPU, RCCL over xGMI).
+
+Counterpart of what the reference delegates to Lightning (src/sihl/lightning_module.py:68-120 training_step,
+:179-245 configure_optimizers, examples/object_detection.py:288-296 Trainer flags):
+  * loss = sum of the heads' training_step losses on ONE extract_features pass,
+  * AdamW parameter groups: backbone lr x backbone_lr_factor, no weight decay on biases / norm parameters,
+  * gradient-norm clipping (gradient_clip_val), bf16 autocast for the backbone with fp32 loss islands,
+  * DP: minibatch sharded across ranks, per-replica BatchNorm statistics (Lightning-DDP default), gradients
+    averaged with bucketed all-reduces launched from grad-ready hooks so they overlap the rest of backward.
+"""
+from typing import Any, Dict, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn
+
+NO_DECAY_TYPES = (nn.LayerNorm, nn.GroupNorm, nn.BatchNorm2d, nn.Embedding)
+
+
+def configure_optimizer(model: nn.Module, optimizer=torch.optim.AdamW, lr: float = 1e-4, weight_decay: float = 1e-4,
+                        backbone_lr_factor: float = 0.1, **kw) -> torch.optim.Optimizer:
+    """Parameter grouping of the reference's configure_optimizers (lightning_module.py:179-222)."""
+    backbone = {id(p) for p in model.backbone.parameters()} if hasattr(model, "backbone") else set()
+    no_decay = set()
+    for m in model.modules():
+        for pn, p in m.named_parameters(recurse=False):
+            if pn.endswith("bias") or isinstance(m, NO_DECAY_TYPES):
+                no_decay.add(id(p))
+    groups: Dict[Any, List[Tensor]] = {}
+    for p in model.parameters():
+        if not p.requires_grad:
+            continue
+        key = (id(p) in backbone, id(p) in no_decay)
+        groups.setdefault(key, []).append(p)
+    param_groups = []
+    for (is_bb, is_nd), params in groups.items():
+        param_groups.append({"params": params, "lr": lr * (backbone_lr_factor if is_bb else 1.0),
+                             "weight_decay": 0.0 if is_nd else weight_decay})
+    return optimizer(param_groups, lr=lr, weight_decay=weight_decay, **kw)
+
+
+class GradientAverager:
+    """Bucketed, overlapped gradient all-reduce (mean) across the data-parallel group.
+
+    Parameters are packed into ~bucket_mb fp32 buckets in REVERSE registration order (roughly the order
+    autograd produces their gradients).  A post-accumulate hook copies each finished gradient into its
+    bucket slice; when a bucket is full its all-reduce is issued asynchronously (RCCL runs it on its own
+    stream over xGMI while backward continues).  ``finish()`` waits and copies the averages back."""
+
+    def __init__(self, params: Sequence[Tensor], group=None, bucket_mb: float = 32.0):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets: List[Dict[str, Any]] = []
+        self.where: Dict[int, Any] = {}
+        if self.world == 1:
+            return
+        cap = int(bucket_mb * (1 << 20) // 4)
+        cur: List[Tensor] = []
+        size = 0
+        for p in reversed(self.params):
+            if cur and size + p.numel() > cap:
+                self._close(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += p.numel()
+        if cur:
+            self._close(cur)
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
+        self.use_avg = dist.get_backend(group) == "nccl"
+
+    def _close(self, ps: List[Tensor]) -> None:
+        n = sum(p.numel() for p in ps)
+        flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
+        b = {"flat": flat, "params": ps, "pending": len(ps), "work": None}
+        off = 0
+        for p in ps:
+            self.where[id(p)] = (b, off)
+            off += p.numel()
+        self.buckets.append(b)
+
+    def _on_grad(self, p: Tensor) -> None:
+        b, off = self.where[id(p)]
+        b["flat"][off: off + p.numel()].view(p.shape).copy_(p.grad)
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
+            b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
+
+    def finish(self) -> None:
+        if self.world == 1:
+            return
+        for b in self.buckets:
+            if b["work"] is None:  # some parameter of this bucket got no gradient this step
+                for p in b["params"]:
+                    _, off = self.where[id(p)]
+                    if p.grad is None:
+                        b["flat"][off: off + p.numel()].zero_()
+                op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
+                b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
+        for b in self.buckets:
+            b["work"].wait()
+            if not self.use_avg:
+                b["flat"].div_(self.world)
+            off = 0
+            for p in b["params"]:
+                n = p.numel()
+                if p.grad is not None:
+                    p.grad.copy_(b["flat"][off: off + n].view(p.shape))
+                off += n
+            b["pending"], b["work"] = len(b["params"]), None
+
+
+def broadcast_parameters(model: nn.Module, src: int = 0, group=None) -> None:
+    """Identical initial replicas: rank ``src``'s parameters and buffers are sent to every rank once."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for t in list(model.parameters()) + list(model.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
+
+
+class Trainer:
+    """One optimisation step = forward (backbone -> neck -> heads' training_step) + backward +
+    gradient all-reduce + clip + optimizer step."""
+
+    def __init__(self, model: nn.Module, optimizer: Optional[torch.optim.Optimizer] = None, group=None,
+                 grad_clip_norm: Optional[float] = 0.1, autocast_dtype: Optional[torch.dtype] = None,
+                 bucket_mb: float = 32.0, **opt_kw):
+        self.model = model
+        self.optimizer = optimizer or configure_optimizer(model, **opt_kw)
+        self.grad_clip_norm = grad_clip_norm
+        self.autocast_dtype = autocast_dtype
+        broadcast_parameters(model, group=group)
+        self.averager = GradientAverager(list(model.parameters()), group=group, bucket_mb=bucket_mb)
+
+    def forward_loss(self, images: Tensor, targets: List[Any]):
+        dev_type = images.device.type
+        if self.autocast_dtype is not None:
+            # the backbone runs under autocast (ATen / MIOpen); the neck and heads take its bf16 level list
+            with torch.autocast(device_type=dev_type, dtype=self.autocast_dtype):
+                levels = self.model.backbone(images)
+            levels = [t if i == 0 else t.to(self.autocast_dtype) for i, t in enumerate(levels)]
+            feats = self.model.neck(levels) if self.model.neck is not None else levels
+        else:
+            feats = self.model.extract_features(images)
+        losses, metrics = [], {}
+        for i, (head, target) in enumerate(zip(self.model.heads, targets)):
+            loss, m = head.training_step(feats, **target) if isinstance(target, dict) else head.training_step(feats, target)
+            losses.append(loss)
+            metrics.update({f"head{i}/train/{k}": v for k, v in m.items()})
+        return torch.stack(losses).sum(), metrics
+
+    def step(self, images: Tensor, targets: List[Any]):
+        self.model.train()
+        self.optimizer.zero_grad(set_to_none=True)
+        loss, metrics = self.forward_loss(images, targets)
+        loss.backward()
+        self.averager.finish()
+        if self.grad_clip_norm is not None:
+            torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.grad is not None],
+                                           self.grad_clip_norm)
+        self.optimizer.step()
+        return loss.detach(), metrics

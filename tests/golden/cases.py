@@ -53,7 +53,7 @@ def _levels(seed: int, batch: int, chans: List[int], size: int, used: range) -> 
 
 
 def _grads(outs: List[Tensor], cots: List[Tensor], wrt: List[Tensor]) -> List[Tensor]:
-    loss = sum((o * c).sum() for o, c in zip(outs, cots))
+    loss = sum((o * c.to(o.device, o.dtype)).sum() for o, c in zip(outs, cots))
     return torch.autograd.grad(loss, wrt, allow_unused=True)
 
 
@@ -220,7 +220,9 @@ def od_targets():
 
 def _od_train_run(m, inp):
     lv = [t.clone().requires_grad_(i >= 3) for i, t in enumerate(inp["levels"])]
+    dev = lv[3].device
     classes, boxes = od_targets()
+    classes, boxes = [c.to(dev) for c in classes], [b.to(dev) for b in boxes]
     loss, metrics = m.training_step(lv, classes, boxes)
     res = {"loss": loss, **{k: v for k, v in metrics.items()}}
     params = [(n, p) for n, p in m.named_parameters()]
@@ -238,7 +240,9 @@ _register("od_training_step", _od_build, _od_inputs, _od_train_run, True, needs=
 
 def _od_nogt_run(m, inp):
     lv = [t.clone() for t in inp["levels"]]
-    loss, metrics = m.training_step(lv, [torch.zeros(0, dtype=torch.int64)] * 3, [torch.zeros(0, 4)] * 3)
+    dev = lv[3].device
+    loss, metrics = m.training_step(lv, [torch.zeros(0, dtype=torch.int64, device=dev)] * 3,
+                                    [torch.zeros(0, 4, device=dev)] * 3)
     return {"loss": loss, **metrics}
 
 
@@ -251,10 +255,11 @@ def _matching_inputs():
 
 def _matching_run(m, inp):
     off, scl = m.get_offsets_and_scales(inp["levels"])
-    anchors = (off + scl) * torch.tensor([[128, 128, 128, 128]])
+    anchors = (off + scl) * torch.tensor([[128, 128, 128, 128]], device=off.device)
     res = {"anchors": anchors}
     _, boxes = od_targets()
     for b, gt in enumerate(boxes):
+        gt = gt.to(anchors.device)
         a, r = m.bbox_matching(anchors, gt, 9, relative=True)
         a2, i2 = m.bbox_matching(anchors, gt, 9, relative=False)
         res[f"assign{b}"], res[f"rel_iou{b}"], res[f"iou{b}"] = a, r, i2
@@ -287,7 +292,7 @@ def _ss_forward_run(m, inp):
 def _ss_train_run(m, inp):
     lv = [t.clone().requires_grad_(i >= 3) for i, t in enumerate(inp["levels"])]
     g = torch.Generator().manual_seed(111)
-    targets = torch.randint(0, 7, (2, 64, 64), generator=g)
+    targets = torch.randint(0, 7, (2, 64, 64), generator=g).to(lv[3].device)
     loss, _ = m.training_step(lv, targets)
     res = {"loss": loss}
     params = [(n, p) for n, p in m.named_parameters()]

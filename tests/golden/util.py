@@ -49,3 +49,30 @@ def replay(case, ns, data, device="cpu", dtype=torch.float32, prepare=None):
     inp = {k: mv(v) for k, v in golden_inputs(data).items()}
     res = case.run(m, inp)
     return m, {k: v.detach().float().cpu() if v.is_floating_point() else v.detach().cpu() for k, v in res.items()}
+
+
+def namespace_of(*modules):
+    """Collect the classes of some modules into one attribute namespace (what a case's build() takes)."""
+    class NS:
+        pass
+
+    for mod in modules:
+        for k, v in vars(mod).items():
+            if isinstance(v, type):
+                setattr(NS, k, v)
+    return NS
+
+
+def quantized_copy(data):
+    """Golden data with the inputs and every conv / linear weight rounded to bf16 (kept as fp32).
+
+    Evaluating the fp32 oracle on this copy separates kernel error from operand quantisation: a
+    bf16 run and this oracle see the same operands, so ReLU masks agree except where intermediate
+    rounding differs."""
+    out = dict(data)
+    for k, v in data.items():
+        is_in = k.startswith("in.") and v.dtype == np.float32
+        is_w = k.startswith("sd.") and k.endswith("weight") and v.ndim >= 2
+        if is_in or is_w:
+            out[k] = torch.from_numpy(v.copy()).bfloat16().float().numpy()
+    return out
