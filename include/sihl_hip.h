@@ -1,0 +1,166 @@
+/* sihl_hip.h - C ABI of the MI355X (gfx950) kernels behind sihl's backbone -> FPN/BiFPN -> dense-head hot path.
+ *
+ * The reference (jonregef/sihl, /root/reference/src/sihl) is pure Python: there is no FFI to mirror, the
+ * "plugin interface" is nn.Module duck typing.  This header is therefore the boundary a
+ * maintainer binds instead of the ATen calls each reference line makes; every entry cites the reference
+ * code it replaces.  Binding example (ctypes, what sihl_amd/_C.py does): INTEGRATION.md.
+ *
+ * Conventions
+ *   - layout: activations are NHWC ([N][H][W][C], torch.channels_last storage); weights [Cout][KH][KW][Cin];
+ *     rows x C matrices for the MLP heads.  C must be a multiple of the 16-byte vector (4 fp32 / 8 bf16)
+ *     unless an entry says otherwise.
+ *   - dtype: SIHL_F32 (exact fp32 MFMA, the 1e-4 parity configuration) or SIHL_BF16 (bf16 storage, fp32
+ *     accumulation).  Statistics, norm parameters and every gradient of a parameter are fp32.
+ *   - ownership: every buffer is caller-owned device memory (PyTorch's caching allocator in sihl_amd);
+ *     kernels never allocate.  Scratch comes in through (ws, ws_bytes); the *_ws_bytes helpers size it.
+ *   - streams: every launch goes to the hipStream_t argument, no implicit synchronisation, no global
+ *     mutable state except the opt-in launch profiler; entries are re-entrant.
+ *   - errors: 0 = ok, SIHL_EARG (-1) = bad argument / unsupported shape, SIHL_EWS (-2) = workspace too
+ *     small, > 0 = hipError_t.  Nothing throws across the ABI.
+ */
+#ifndef SIHL_HIP_H
+#define SIHL_HIP_H
+
+#include <hip/hip_runtime_api.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIHL_F32 0
+#define SIHL_BF16 1
+#define SIHL_ACT_NONE 0
+#define SIHL_ACT_RELU 1
+#define SIHL_ACT_SILU 2
+#define SIHL_ACT_SIGMOID 3
+#define SIHL_EARG (-1)
+#define SIHL_EWS (-2)
+
+/* ---- convolution / linear on the matrix cores ------------------------------------------------------------
+ * Replaces nn.Conv2d + activation + norm-apply of ConvNormAct (layers/convblocks.py:37-87), torchvision
+ * Conv2dNormActivation (layers/fpn.py:26-37, heads/object_detection.py:52-55) and nn.Linear inside ops.MLP
+ * (heads/object_detection.py:51-61; a Linear is a 1x1 conv over rows: N=1, H=1, W=rows).
+ * out[m][co] = post( act( pre( conv(in, wt)[m][co] + bias[co] ) ) ), pre/post = per-channel scale*x+shift
+ * (any of bias/pre_/post_ may be NULL).  stats_mode 1 / 2 additionally writes per-channel (sum, sumsq)
+ * partials of the value after bias / after the activation to stats_ws [sihl_conv2d_stat_rows(M)][2][Cout]
+ * (BatchNorm batch statistics, one deterministic row per 128-pixel tile).  out_image_stride (elements,
+ * 0 = dense) lets the head's laterals write into a slice of the flat (B, P, C) position buffer
+ * (object_detection.py:102-105).  Cout is unconstrained; Cin % vector == 0. */
+int sihl_conv2d_stat_rows(long M);
+int sihl_conv2d_fwd(const void* in, const void* wt, const float* bias, void* out, int N, int H, int W, int Cin,
+                    int Cout, int KH, int KW, int stride, int pad, int dil, int dtype, int act,
+                    const float* pre_scale, const float* pre_shift, const float* post_scale,
+                    const float* post_shift, int stats_mode, float* stats_ws, long stats_ws_bytes,
+                    long out_image_stride, hipStream_t stream);
+
+/* Weight gradient (autograd of Conv2d.weight / Linear.weight): dw fp32 [Cout][KH][KW][Cin];
+ * accumulate != 0 adds into dw.  Cin, Cout % vector == 0. */
+long sihl_conv2d_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                int dil, int dtype);
+int sihl_conv2d_wgrad(const void* in, const void* dout, float* dw, int N, int H, int W, int Cin, int Cout, int KH,
+                      int KW, int stride, int pad, int dil, int dtype, int accumulate, void* ws, long ws_bytes,
+                      hipStream_t stream);
+
+/* [Cout][KH][KW][Cin] -> [Cin][KH][KW][Cout], spatially flipped when flip != 0: the weights with which
+ * sihl_conv2d_fwd computes the INPUT gradient of a stride-1 conv (pad' = dil*(K-1) - pad) or of a Linear. */
+int sihl_weight_flip_transpose(const void* w, void* o, int Cout, int KH, int KW, int Cin, int flip, int dtype_in,
+                               int dtype_out, hipStream_t stream);
+
+/* ---- BatchNorm2d (convblocks.py:82-85; torch defaults eps 1e-5, momentum 0.1) ------------------------------
+ * finalize: partial sums -> batch mean / rstd (biased variance), scale = gamma*rstd, shift = beta - mean*scale,
+ * running_mean / running_var updated in place (unbiased variance), any of them may be NULL.
+ * eval_affine: scale / shift from the running statistics. */
+int sihl_bn_finalize(const float* partials, int n_partials, int C, long count, const float* gamma, const float* beta,
+                     float eps, float momentum, float* running_mean, float* running_var, float* mean, float* rstd,
+                     float* scale, float* shift, hipStream_t stream);
+int sihl_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                        float eps, int C, float* scale, float* shift, hipStream_t stream);
+
+/* y = act(x*scale[c] + shift[c]) over [rows][C] (norm-apply; stand-alone SiLU / sigmoid), and its input gradient. */
+int sihl_affine_act(const void* x, void* y, long rows, int C, const float* scale, const float* shift, int act,
+                    int dtype, hipStream_t stream);
+int sihl_affine_act_bwd(const void* x, const void* dy, void* dx, long rows, int C, const float* scale,
+                        const float* shift, int act, int dtype, hipStream_t stream);
+
+/* Backward through [activation -> BatchNorm] (mode 0, ConvNormAct: s = act(conv)) or [BatchNorm -> activation]
+ * (mode 1, Conv2dNormActivation: s = conv): dz = grad wrt the conv output, dgamma / dbeta fp32 [C].
+ * batch_stats != 0 includes the batch-mean / variance terms (training mode). */
+long sihl_norm_act_bwd_ws_bytes(long rows, int C, int dtype);
+int sihl_norm_act_bwd(const void* s, const void* dy, void* dz, long rows, int C, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, float* dgamma, float* dbeta, int mode, int act,
+                      int batch_stats, int dtype, float* ws, long ws_bytes, hipStream_t stream);
+
+/* ---- BiFPN fusion nodes, fused with their producer (layers/bifpn.py:10-17,39-53) --------------------------
+ * w = softmax(wraw) exactly as FastNormalizedFusion (bifpn.py:16); wraw is the raw nn.Parameter (fp32).
+ * fuse_up2 : out[N][H][W][C] = w0 * bilinear_x2(a[N][H/2][W/2][C]) + w1 * b   (Interpolate scale=2,
+ *            align_corners=False, scalers.py:36-47).  b == NULL: plain upsample.
+ * blur_fuse: out = w0 * blurpool(a) + w1 * b + w2 * c with blurpool = reflect-pad 1, [1,2,1]x[1,2,1]/16, stride 2
+ *            (layers/pooling.py:7-26).  b == c == NULL: plain BlurPool2d.
+ * fuse_sum : stand-alone FastNormalizedFusion of n = 2 or 3 tensors.
+ * *_bwd    : input gradients (NULL = not needed) and dw_raw (softmax Jacobian applied); gacc = 2 / 3 floats. */
+int sihl_fuse_up2(const void* a, const void* b, const float* wraw, void* out, int N, int H, int W, int C, int dtype,
+                  hipStream_t stream);
+int sihl_fuse_up2_bwd(const void* dout, const void* a, const void* b, const float* wraw, void* da, void* db,
+                      float* dw_raw, float* gacc, int N, int H, int W, int C, int dtype, hipStream_t stream);
+int sihl_blur_fuse(const void* a, const void* b, const void* c, const float* wraw, void* out, int N, int H, int W,
+                   int C, int dtype, hipStream_t stream);
+int sihl_blur_fuse_bwd(const void* dout, const void* a, const void* b, const void* c, const float* wraw, void* da,
+                       void* db, void* dc, float* dw_raw, float* gacc, int N, int H, int W, int C, int dtype,
+                       hipStream_t stream);
+int sihl_fuse_sum(const void* x0, const void* x1, const void* x2, const float* wraw, void* out, long numel, int n,
+                  int dtype, hipStream_t stream);
+int sihl_fuse_sum_bwd(const void* dout, const void* x0, const void* x1, const void* x2, const float* wraw, void* d0,
+                      void* d1, void* d2, float* dw_raw, float* gacc, long numel, int n, int dtype,
+                      hipStream_t stream);
+
+/* ---- FPN / SPPM resampling (layers/fpn.py:43-48; heads/semantic_segmentation.py:139,154) -------------------
+ * nearest_up2_add: out[N][H][W][C] = nearest_x2(lo) + skip; its backward returns the 2x2 block sums (the skip
+ * gradient is dout itself).  resize_bilinear: any size, align_corners=False, optional "+ add". */
+int sihl_nearest_up2_add(const void* lo, const void* skip, void* out, int N, int H, int W, int C, int dtype,
+                         hipStream_t stream);
+int sihl_nearest_up2_add_bwd(const void* dout, void* dlo, int N, int H, int W, int C, int dtype, hipStream_t stream);
+int sihl_resize_bilinear(const void* a, const void* add, void* out, int N, int H, int W, int Ho, int Wo, int C,
+                         int dtype, hipStream_t stream);
+int sihl_resize_bilinear_bwd(const void* dout, void* da, int N, int H, int W, int Ho, int Wo, int C, int dtype,
+                             hipStream_t stream);
+
+/* ---- MLP hidden layers: y = act(LayerNorm(z)*gamma + beta) over [rows][C] (object_detection.py:51-61) ----- */
+int sihl_layernorm_act(const void* z, void* y, long rows, int C, const float* gamma, const float* beta, float eps,
+                       int act, float* mean, float* rstd, int dtype, hipStream_t stream);
+int sihl_layernorm_bwd_waves(long rows);
+long sihl_layernorm_act_bwd_ws_bytes(long rows, int C);
+int sihl_layernorm_act_bwd(const void* z, const void* dy, void* dz, long rows, int C, const float* gamma,
+                           const float* beta, const float* mean, const float* rstd, int act, float* dgamma,
+                           float* dbeta, int dtype, float* ws, long ws_bytes, hipStream_t stream);
+
+/* out[c] = sum_r x[r][c] (bias gradients). */
+long sihl_colsum_ws_bytes(long rows, int C);
+int sihl_colsum(const void* x, long rows, int C, float* out, int dtype, float* ws, long ws_bytes, hipStream_t stream);
+
+/* ---- ObjectDetection.forward decode (heads/object_detection.py:99-122, anchors :83-97) ---------------------
+ * topk_rows : per image, the K largest of P position logits (estride elements apart), sorted descending
+ *             (object_detection.py:109); vals fp32 [B][K], idx int32 [B][K].
+ * gather_rows: out[b][k][:] = src[b][idx[b][k]][:]                                   (:110-112)
+ * od_decode : scores = sigmoid(vals), num_instances = #(scores > 0.5), classes = argmax(cls_logits),
+ *             boxes = (offsets + scales*exp(box_raw)) * (W,H,W,H) with closed-form cell anchors (:113-121);
+ *             level_hw is a HOST array [n_levels][2] of (h, w), bottom level first.
+ * od_anchors: the (P,4) offsets / scales tensors of get_offsets_and_scales (:83-97), for the training loss. */
+int sihl_topk_rows(const void* x, int B, int P, int K, int estride, float* vals, int* idx, int dtype,
+                   hipStream_t stream);
+int sihl_gather_rows(const void* src, const int* idx, void* out, int B, int P, int K, int C, int dtype,
+                     hipStream_t stream);
+int sihl_od_decode(const float* top_vals, const int* top_idx, const void* cls_logits, const void* box_raw,
+                   const int* level_hw, int n_levels, int B, int K, int ncls, int full_w, int full_h, float* scores,
+                   long* classes, float* boxes, long* num_instances, int dtype, hipStream_t stream);
+int sihl_od_anchors(const int* level_hw, int n_levels, float* offsets, float* scales, hipStream_t stream);
+
+/* ---- opt-in launch profiler (bench.py roofline leg): HIP events around the matrix-core launches ------------
+ * slot 0 = conv (fwd / dgrad / linear), slot 1 = wgrad. */
+int sihl_profile_enable(int on);
+int sihl_profile_collect(int slot, int dtype, long* launches, double* total_ms, double* total_flops,
+                         double* total_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIHL_HIP_H */

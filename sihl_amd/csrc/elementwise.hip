@@ -677,13 +677,26 @@ __global__ void norm_bwd_reduce_kernel(const T* __restrict__ s, const T* __restr
   }
 }
 
-// out[k][c] = sum_r part[r][k][c]   (k < K)
+// out[k][c] = sum_r part[r][k][c]   (k < K).  256 threads = 64 columns x 4 row lanes, fp32 partials summed
+// in double, then the 4 lanes are combined through LDS.
 __global__ void colsum_finalize_kernel(const float* __restrict__ part, int R, int K, int C, float* __restrict__ out) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= K * C) return;
-  double s = 0.0;
-  for (int r = 0; r < R; ++r) s += (double)part[(long)r * K * C + idx];
-  out[idx] = (float)s;
+  __shared__ double sh[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + cx, KC = K * C;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (idx < KC) {
+    int r = ry;
+    for (; r + 12 < R; r += 16) {
+      s0 += (double)part[(long)r * KC + idx];
+      s1 += (double)part[(long)(r + 4) * KC + idx];
+      s2 += (double)part[(long)(r + 8) * KC + idx];
+      s3 += (double)part[(long)(r + 12) * KC + idx];
+    }
+    for (; r < R; r += 4) s0 += (double)part[(long)r * KC + idx];
+  }
+  sh[ry][cx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ry == 0 && idx < KC) out[idx] = (float)(sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx]);
 }
 
 // dz for conv->act->BN (mode 0) or conv->BN->act (mode 1); batch_stats: include the mean/var terms
@@ -1086,7 +1099,7 @@ int sihl_blur_fuse_bwd(const void* dout, const void* a, const void* b, const voi
 // mode 1: s = conv (pre-norm), y = act(BN(s)).  Writes dgamma/dbeta (fp32 [C]) and dz (grad wrt conv output).
 static int reduce_blocks(long rows) {
   long nb = (rows + 255) / 256;
-  if (nb > 1024) nb = 1024;
+  if (nb > 256) nb = 256;
   if (nb < 1) nb = 1;
   return (int)nb;
 }
@@ -1113,7 +1126,7 @@ int sihl_norm_act_bwd(const void* s, const void* dy, void* dz, long rows, int C,
     if (C % V) return SIHL_EARG;
     hipLaunchKernelGGL(norm_bwd_reduce_kernel<T>, dim3(nblk), dim3(TPB), 0, stream, (const T*)s, (const T*)dy, rows, C,
                        mean, rstd, gamma, beta, mode, act, ws, rpb, nrl);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, (const float*)ws,
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, stream, (const float*)ws,
                        nblk * nrl, 2, C, sums);
     const long nvec = rows * (C / V);
     hipLaunchKernelGGL(norm_bwd_apply_kernel<T>, dim3(grid_for(nvec)), dim3(TPB), 0, stream, (const T*)s,
@@ -1166,7 +1179,7 @@ int sihl_layernorm_act_bwd(const void* z, const void* dy, void* dz, long rows, i
     hipLaunchKernelGGL(layernorm_act_bwd_kernel<T>, dim3(nwaves / 4), dim3(TPB), 0, stream, (const T*)z, (const T*)dy,
                        (T*)dz, rows, C, gamma, beta, mean, rstd, act, ws);
   });
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, (const float*)ws, nwaves,
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, stream, (const float*)ws, nwaves,
                      2, C, sums);
   if (dbeta) { hipError_t e = hipMemcpyAsync(dbeta, sums, C * sizeof(float), hipMemcpyDeviceToDevice, stream); if (e) return (int)e; }
   if (dgamma) { hipError_t e = hipMemcpyAsync(dgamma, sums + C, C * sizeof(float), hipMemcpyDeviceToDevice, stream); if (e) return (int)e; }
@@ -1183,7 +1196,7 @@ int sihl_colsum(const void* x, long rows, int C, float* out, int dtype, float* w
   DISPATCH_DTYPE(dtype, {
     hipLaunchKernelGGL(colsum_partial_kernel<T>, dim3(nblk), dim3(TPB), 0, stream, (const T*)x, rows, C, ws, rpb, nrl);
   });
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)ws,
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, (const float*)ws,
                      nblk * nrl, 1, C, out);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;

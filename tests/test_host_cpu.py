@@ -1,0 +1,157 @@
+"""CPU: host logic, the C-ABI surface and the no-fallback rule (no GPU compute here)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import oracle
+import sihl_amd
+from sihl_amd import _C
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_prototypes():
+    text = open(os.path.join(ROOT, "include", "sihl_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|long)\s+(sihl_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        args = [a.strip() for a in m.group(3).split(",") if a.strip() and a.strip() != "void"]
+        protos[m.group(2)] = args
+    return protos
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_C.LIB_PATH)
+    protos = _header_prototypes()
+    assert len(protos) >= 30
+    for name in protos:
+        assert hasattr(lib, name), f"{name} declared in include/sihl_hip.h but not exported"
+
+
+def test_binding_matches_header():
+    protos = _header_prototypes()
+    assert set(_C.SIGNATURES) == set(protos), sorted(set(_C.SIGNATURES) ^ set(protos))
+    for name, (_, argtypes) in _C.SIGNATURES.items():
+        assert len(argtypes) == len(protos[name]), name
+        for at, decl in zip(argtypes, protos[name]):
+            if "*" in decl or "hipStream_t" in decl:
+                assert at is ctypes.c_void_p, (name, decl)
+            elif decl.startswith("long"):
+                assert at is ctypes.c_long, (name, decl)
+            elif decl.startswith("float"):
+                assert at is ctypes.c_float, (name, decl)
+            else:
+                assert at is ctypes.c_int, (name, decl)
+    _C.lib()  # resolves every symbol
+
+
+def test_argument_errors_without_gpu():
+    lib = _C.lib()
+    assert lib.sihl_conv2d_stat_rows(131072) == 1024
+    assert lib.sihl_conv2d_fwd(None, None, None, None, 1, 1, 1, 8, 8, 1, 1, 1, 0, 1, 0, 0, None, None, None, None,
+                               0, None, 0, 0, None) == -1
+    assert lib.sihl_topk_rows(None, 1, 10, 5, 1, None, None, 0, None) == -1
+    assert lib.sihl_conv2d_wgrad_ws_bytes(32, 64, 64, 256, 256, 3, 3, 1, 1, 1, 1) > 0
+
+
+def test_no_cpu_fallback():
+    neck = sihl_amd.layers.BiFPN([3, 8, 8, 16, 32, 64], 16, 3, 5)
+    levels = [torch.zeros(1, c, 64 // 2 ** i, 64 // 2 ** i) for i, c in enumerate([3, 8, 8, 16, 32, 64])]
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        neck(levels)
+
+
+@pytest.mark.parametrize("build", [
+    lambda ns: ns.BiFPN([3, 64, 256, 512, 1024, 2048], 256, 3, 7),
+    lambda ns: ns.FPN([3, 64, 256, 512, 1024, 2048], 256, 3, 5),
+    lambda ns: ns.FPN([3, 64, 256, 512, 1024, 2048], 256, 3, 7),
+    lambda ns: ns.ObjectDetection([3, 64, 256] + [256] * 5, 80, 3, 7),
+    lambda ns: ns.ResNetBackbone("resnet50"),
+    lambda ns: ns.ResNetBackbone("resnet18", top_level=7),
+])
+def test_state_dict_layout_matches_oracle(build):
+    class HIP:
+        pass
+
+    class ORA:
+        pass
+
+    for ns, mods in ((HIP, (sihl_amd.layers, sihl_amd.heads, sihl_amd)), (ORA, (oracle,))):
+        for mod in mods:
+            for k, v in vars(mod).items():
+                if isinstance(v, type):
+                    setattr(ns, k, v)
+    a, b = build(HIP), build(ORA)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert list(sa) == list(sb)
+    for k in sa:
+        assert tuple(sa[k].shape) == tuple(sb[k].shape), k
+    b.load_state_dict(sa)  # and the other way round
+    if hasattr(a, "out_channels"):
+        assert a.out_channels == b.out_channels
+
+
+def test_reference_parameter_counts():
+    """23 351 868 (BiFPN), 1 413 206 (OD head, 80 classes), 2 822 144 (FPN 3-5) measured on the reference."""
+    ch = [3, 64, 256, 512, 1024, 2048]
+    n = lambda m: sum(p.numel() for p in m.parameters())
+    neck = sihl_amd.layers.BiFPN(ch, 256, 3, 7)
+    assert n(neck) == 23_351_868
+    assert neck.out_channels == [3, 64, 256, 256, 256, 256, 256, 256]
+    assert n(sihl_amd.heads.ObjectDetection(neck.out_channels, 80, 3, 7)) == 1_413_206
+    assert n(sihl_amd.layers.FPN(ch, 256, 3, 5)) == 2_822_144
+    head = sihl_amd.heads.ObjectDetection(neck.out_channels, 80, 3, 7)
+    assert len(head.loc_head) == 18 and float(head.loc_head[-2].bias[0]) == -5.0
+
+
+def test_config1_plumbing_on_cpu():
+    """BASELINE configs[0]: resnet18 backbone, no neck, 10-class head, bs=8 3x224x224 synthetic, CPU only."""
+    torch.manual_seed(0)
+    backbone = sihl_amd.TorchvisionBackbone("resnet18")
+    assert backbone.out_channels == [3, 64, 64, 128, 256, 512]
+    head = sihl_amd.heads.MulticlassClassification(backbone.out_channels, num_classes=10)
+    model = sihl_amd.SihlModel(backbone, None, [head])
+    x = torch.rand(8, 3, 224, 224)
+    feats = model.extract_features(x)
+    assert [tuple(f.shape[2:]) for f in feats] == [(224 // 2 ** i,) * 2 for i in range(6)]
+    (scores, classes), = model(x)
+    assert tuple(scores.shape) == (8,) and tuple(classes.shape) == (8,)
+    loss, _ = head.training_step(feats, torch.randint(0, 10, (8,)))
+    loss.backward()
+    assert loss.item() > 0
+    with pytest.raises(ValueError):
+        sihl_amd.TorchvisionBackbone("not_a_net")
+    with pytest.raises(AssertionError):
+        backbone(torch.rand(1, 3, 100, 100))  # not divisible by 2**top_level (torchvision_backbone.py:174-175)
+
+
+def test_optimizer_groups_follow_reference():
+    from sihl_amd.train import configure_optimizer
+
+    backbone = oracle.ResNetBackbone("resnet18")
+    neck = oracle.BiFPN(backbone.out_channels, 32, 3, 5, num_layers=1)
+    head = oracle.ObjectDetection(neck.out_channels, 4, 3, 5, num_channels=32)
+    model = oracle.SihlModel(backbone, neck, [head])
+    opt = configure_optimizer(model, lr=1e-4, weight_decay=1e-4, backbone_lr_factor=0.1)
+    bb = {id(p) for p in backbone.parameters()}
+    # biases and norm parameters are never decayed (lightning_module.py:196-204); the 1-D fusion weights
+    # ("...weights") are neither, so the reference decays them and so do we
+    no_decay = set()
+    for m in model.modules():
+        for pn, p in m.named_parameters(recurse=False):
+            if pn.endswith("bias") or isinstance(m, (torch.nn.BatchNorm2d, torch.nn.LayerNorm)):
+                no_decay.add(id(p))
+    seen = 0
+    for g in opt.param_groups:
+        is_bb = {id(p) in bb for p in g["params"]}
+        assert len(is_bb) == 1
+        assert g["lr"] == pytest.approx(1e-5 if is_bb.pop() else 1e-4)
+        for p in g["params"]:
+            seen += 1
+            assert g["weight_decay"] == (0.0 if id(p) in no_decay else 1e-4)
+    assert seen == len(list(model.parameters()))
+    fusion = [p for n, p in model.named_parameters() if n.endswith("fusions.0.weights")]
+    assert fusion and all(id(p) not in no_decay for p in fusion)
