@@ -154,6 +154,24 @@ int sihl_od_decode(const float* top_vals, const int* top_idx, const void* cls_lo
                    long* classes, float* boxes, long* num_instances, int dtype, hipStream_t stream);
 int sihl_od_anchors(const int* level_hw, int n_levels, float* offsets, float* scales, hipStream_t stream);
 
+/* ---- SemanticSegmentation head (heads/semantic_segmentation.py) -------------------------------------------------
+ * uafm_fwd: UAFM (:163-182): out = x1*a + x2*(1-a), a = sigmoid(conv3x3_{4->1}([mean_c x1, max_c x1, mean_c x2,
+ *   max_c x2]) + b); conv_w is the (1,4,3,3) weight (fp32, contiguous), conv_b one float or NULL.  stats
+ *   [N][H][W][4] fp32, arg [N][H][W][2] int32 (argmax channels), alpha [N][H][W] fp32 are outputs kept for uafm_bwd.
+ * softmax_max_resize: forward (:83-85) = nearest resize of the logits to (H, W) + softmax + max, fused; any C.
+ * ce_resize: training_step (:87-92) = nearest resize to the target size + cross_entropy(ignore_index), fused:
+ *   acc = (sum of per-pixel losses, #valid targets); dl = d(sum loss)/d logits * inv_count[0]. */
+int sihl_uafm_fwd(const void* x1, const void* x2, const float* conv_w, const float* conv_b, void* out, float* stats,
+                  int* arg, float* alpha, int N, int H, int W, int C, int dtype, hipStream_t stream);
+long sihl_uafm_bwd_ws_bytes(int N, int H, int W);
+int sihl_uafm_bwd(const void* dout, const void* x1, const void* x2, const float* conv_w, const float* stats,
+                  const int* arg, const float* alpha, void* dx1, void* dx2, float* dconv_w, float* dconv_b, int N,
+                  int H, int W, int C, int dtype, float* ws, long ws_bytes, hipStream_t stream);
+int sihl_softmax_max_resize(const void* logits, float* scores, long* classes, int N, int h, int w, int C, int H,
+                            int W, int dtype, hipStream_t stream);
+int sihl_ce_resize(const void* logits, const long* targets, long ignore_index, const float* inv_count, void* dl,
+                   float* acc, int N, int h, int w, int C, int H, int W, int dtype, hipStream_t stream);
+
 /* ---- opt-in launch profiler (bench.py roofline leg): HIP events around the matrix-core launches ------------
  * slot 0 = conv (fwd / dgrad / linear), slot 1 = wgrad. */
 int sihl_profile_enable(int on);

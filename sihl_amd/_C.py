@@ -49,6 +49,11 @@ SIGNATURES = {
     "sihl_gather_rows": (I, [P, P, P, I, I, I, I, I, P]),
     "sihl_od_decode": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, I, P]),
     "sihl_od_anchors": (I, [P, I, P, P, P]),
+    "sihl_uafm_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "sihl_uafm_bwd_ws_bytes": (L, [I, I, I]),
+    "sihl_uafm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, L, P]),
+    "sihl_softmax_max_resize": (I, [P, P, P, I, I, I, I, I, I, I, P]),
+    "sihl_ce_resize": (I, [P, P, L, P, P, P, I, I, I, I, I, I, I, P]),
     "sihl_profile_enable": (I, [I]),
     "sihl_profile_collect": (I, [I, I, P, P, P, P]),
 }

@@ -2,3 +2,4 @@
 from sihl_amd.heads.mlp import MLP  # noqa: F401
 from sihl_amd.heads.multiclass_classification import MulticlassClassification  # noqa: F401
 from sihl_amd.heads.object_detection import ObjectDetection  # noqa: F401
+from sihl_amd.heads.semantic_segmentation import SPPM, UAFM, SemanticSegmentation  # noqa: F401

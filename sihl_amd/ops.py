@@ -610,3 +610,89 @@ def od_anchors(level_hw, device):
     rc = _C.lib().sihl_od_anchors(_levels_arr(level_hw), len(level_hw), _p(offsets), _p(scales), _stream())
     check(rc, "sihl_od_anchors")
     return offsets, scales
+
+
+# ----------------------------------------------------------------------------- semantic-segmentation pieces
+class UAFMFn(torch.autograd.Function):
+    """out = x1*a + x2*(1-a), a = sigmoid(conv3x3_{4->1}(channel mean/max of x1 and x2) + b)  (NHWC)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, conv_w, conv_b):
+        x1, x2 = x1.detach().contiguous(), x2.detach().contiguous()
+        N, H, W, C = x1.shape
+        w = conv_w.detach().float().contiguous()  # (1,4,3,3) OIHW
+        b = conv_b.detach().float().contiguous() if conv_b is not None else None
+        dev = x1.device
+        out = torch.empty_like(x1)
+        stats = torch.empty((N, H, W, 4), dtype=torch.float32, device=dev)
+        arg = torch.empty((N, H, W, 2), dtype=torch.int32, device=dev)
+        alpha = torch.empty((N, H, W), dtype=torch.float32, device=dev)
+        rc = _C.lib().sihl_uafm_fwd(_p(x1), _p(x2), _p(w), _p(b), _p(out), _p(stats), _p(arg), _p(alpha), N, H, W, C,
+                                    _dt(x1), _stream())
+        check(rc, "sihl_uafm_fwd")
+        ctx.save_for_backward(x1, x2, w, stats, arg, alpha)
+        ctx.has_bias = b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x1, x2, w, stats, arg, alpha = ctx.saved_tensors
+        dout = dout.contiguous()
+        N, H, W, C = x1.shape
+        lib = _C.lib()
+        ws = workspace(lib.sihl_uafm_bwd_ws_bytes(N, H, W), x1.device)
+        dx1 = torch.empty_like(x1) if ctx.needs_input_grad[0] else None
+        dx2 = torch.empty_like(x2) if ctx.needs_input_grad[1] else None
+        dw = torch.empty(36, dtype=torch.float32, device=x1.device)
+        db = torch.empty(1, dtype=torch.float32, device=x1.device)
+        rc = lib.sihl_uafm_bwd(_p(dout), _p(x1), _p(x2), _p(w), _p(stats), _p(arg), _p(alpha), _p(dx1), _p(dx2),
+                               _p(dw), _p(db), N, H, W, C, _dt(x1), _p(ws), ws.numel(), _stream())
+        check(rc, "sihl_uafm_bwd")
+        return dx1, dx2, dw.view(1, 4, 3, 3), db if ctx.has_bias else None
+
+
+def uafm(x1, x2, conv_w, conv_b):
+    return UAFMFn.apply(x1, x2, conv_w, conv_b)
+
+
+def softmax_max_resize(logits: Tensor, size):
+    """logits (N,h,w,C) -> (scores fp32 (N,H,W), classes int64 (N,H,W)): nearest resize + softmax + max."""
+    logits = logits.detach().contiguous()
+    _require_gpu(logits)
+    N, h, w, C = logits.shape
+    H, W = size
+    scores = torch.empty((N, H, W), dtype=torch.float32, device=logits.device)
+    classes = torch.empty((N, H, W), dtype=torch.int64, device=logits.device)
+    rc = _C.lib().sihl_softmax_max_resize(_p(logits), _p(scores), _p(classes), N, h, w, C, H, W, _dt(logits),
+                                          _stream())
+    check(rc, "sihl_softmax_max_resize")
+    return scores, classes
+
+
+class CEResizeFn(torch.autograd.Function):
+    """mean cross-entropy of nearest-resized logits (N,h,w,C) against targets (N,H,W) with ignore_index."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, ignore_index):
+        lg = logits.detach().contiguous()
+        _require_gpu(lg)
+        N, h, w, C = lg.shape
+        tg = targets.detach().to(torch.int64).contiguous()
+        H, W = tg.shape[1:]
+        inv_count = 1.0 / (tg != ignore_index).sum().to(torch.float32).reshape(1)  # device scalar, no host sync
+        dl = torch.empty_like(lg)
+        acc = torch.empty(2, dtype=torch.float32, device=lg.device)
+        rc = _C.lib().sihl_ce_resize(_p(lg), _p(tg), int(ignore_index), _p(inv_count), _p(dl), _p(acc), N, h, w, C, H,
+                                     W, _dt(lg), _stream())
+        check(rc, "sihl_ce_resize")
+        ctx.save_for_backward(dl)
+        return acc[0] * inv_count[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g.to(dl.dtype), None, None
+
+
+def ce_resize(logits, targets, ignore_index):
+    return CEResizeFn.apply(logits, targets, ignore_index)

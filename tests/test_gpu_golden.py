@@ -10,7 +10,6 @@ from util import golden_results, golden_state_dict, load_npz, replay
 pytestmark = pytest.mark.gpu
 
 INT_KEYS = {"classes", "num_instances", "n_out"}
-NOT_YET = {"semseg", }  # rows of SURVEY §8 not built yet in this round are listed in DESIGN.md
 
 
 def _ns():
@@ -43,7 +42,7 @@ def _compare(name, res, gold, rtol, atol):
             torch.testing.assert_close(r.float(), g.float(), rtol=rtol, atol=a, msg=lambda s: f"{name}:{k}: {s}")
 
 
-@pytest.mark.parametrize("name", _cases({"layers", "fpn", "od"}))
+@pytest.mark.parametrize("name", _cases({"layers", "fpn", "od", "semseg"}))
 def test_hip_fp32_matches_reference(name):
     data = load_npz(name)
     m, res = replay(CASES[name], _ns(), data, device="cuda", dtype=torch.float32)
