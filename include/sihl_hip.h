@@ -53,6 +53,12 @@ int sihl_conv2d_fwd(const void* in, const void* wt, const float* bias, void* out
                     const float* post_shift, int stats_mode, float* stats_ws, long stats_ws_bytes,
                     long out_image_stride, hipStream_t stream);
 
+/* Input gradient of a (possibly strided) conv: din [N][H][W][Cin] from dout [N][Ho][Wo][Cout] with
+ * wt_t = sihl_weight_flip_transpose(w, flip=1) = [Cin][KH][KW][Cout]; (N,H,W,Cin,Cout,...) describe the FORWARD conv.
+ * Same kernel as the forward (dout is read as if zero-dilated by `stride`). */
+int sihl_conv2d_dgrad(const void* dout, const void* wt_t, void* din, int N, int H, int W, int Cin, int Cout, int KH,
+                      int KW, int stride, int pad, int dil, int dtype, hipStream_t stream);
+
 /* Weight gradient (autograd of Conv2d.weight / Linear.weight): dw fp32 [Cout][KH][KW][Cin];
  * accumulate != 0 adds into dw.  Cin, Cout % vector == 0. */
 long sihl_conv2d_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,

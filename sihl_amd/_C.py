@@ -20,6 +20,7 @@ P, I, L, F = c_void_p, c_int, c_long, c_float
 SIGNATURES = {
     "sihl_conv2d_stat_rows": (I, [L]),
     "sihl_conv2d_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, P, P, P, I, P, L, L, P]),
+    "sihl_conv2d_dgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "sihl_conv2d_wgrad_ws_bytes": (L, [I, I, I, I, I, I, I, I, I, I, I]),
     "sihl_conv2d_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, L, P]),
     "sihl_weight_flip_transpose": (I, [P, P, I, I, I, I, I, I, I, P]),

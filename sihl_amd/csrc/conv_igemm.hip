@@ -36,6 +36,7 @@ struct ConvParams {
   int M;
   int act, stats_mode;  // stats_mode: 0 none, 1 after bias (pre-affine), 2 after activation
   long out_image_stride;  // elements between consecutive images of the output (>= Ho*Wo*Cout)
+  int in_dilate;          // >1: the input is read as if zero-dilated by this factor (dgrad of a strided conv)
   int gridM, gridN;
 };
 
@@ -115,8 +116,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const bool ch_ok = ch < p.Cin;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int iy = a_iy0[i] + ky * p.dil, ix = a_ix0[i] + kx * p.dil;
-      const bool ok = ch_ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      int iy = a_iy0[i] + ky * p.dil, ix = a_ix0[i] + kx * p.dil;
+      bool ok = ch_ok && iy >= 0 && ix >= 0;
+      if (p.in_dilate > 1) {
+        ok = ok && (iy % p.in_dilate == 0) && (ix % p.in_dilate == 0);
+        iy /= p.in_dilate;
+        ix /= p.in_dilate;
+      }
+      ok = ok && iy < p.H && ix < p.W;
       ra[i] = ok ? *(const uint4*)(in + a_base[i] + ((long)iy * p.W + ix) * p.Cin + ch) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
@@ -303,6 +310,7 @@ int sihl_conv2d_fwd(const void* in, const void* wt, const float* bias, void* out
   p.M = (int)M;
   p.act = act; p.stats_mode = stats_mode;
   p.gridM = p.gridN = 0;
+  p.in_dilate = 1;
   p.out_image_stride = out_image_stride > 0 ? out_image_stride : (long)p.Ho * p.Wo * Cout;
   if (p.out_image_stride < (long)p.Ho * p.Wo * Cout) return SIHL_EARG;
   if (p.out_image_stride % (dtype == SIHL_BF16 ? 8 : 4)) return SIHL_EARG;
@@ -310,6 +318,38 @@ int sihl_conv2d_fwd(const void* in, const void* wt, const float* bias, void* out
     if (!stats_ws) return SIHL_EARG;
     if (stats_ws_bytes < (long)sihl_conv2d_stat_rows(M) * 2 * Cout * (long)sizeof(float)) return SIHL_EWS;
   }
+  if (dtype == SIHL_F32) return dispatch<float>(p, stream);
+  if (dtype == SIHL_BF16) return dispatch<bf16_t>(p, stream);
+  return SIHL_EARG;
+}
+
+// Input gradient of a (possibly strided) convolution: din[N][H][W][Cin] from dout[N][Ho][Wo][Cout], where
+// wt_t = sihl_weight_flip_transpose(w, flip=1) is [Cin][KH][KW][Cout].  dout is read as if zero-dilated by `stride`.
+int sihl_conv2d_dgrad(const void* dout, const void* wt_t, void* din, int N, int H, int W, int Cin, int Cout, int KH,
+                      int KW, int stride, int pad, int dil, int dtype, hipStream_t stream) {
+  if (!dout || !wt_t || !din || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 ||
+      stride <= 0 || dil <= 0 || pad < 0)
+    return SIHL_EARG;
+  const int pad_d_h = dil * (KH - 1) - pad, pad_d_w = dil * (KW - 1) - pad;
+  if (pad_d_h < 0 || pad_d_h != pad_d_w) return SIHL_EARG;
+  ConvParams p;
+  p.in = dout; p.wt = wt_t; p.out = din; p.bias = nullptr;
+  p.pre_scale = p.pre_shift = p.post_scale = p.post_shift = nullptr;
+  p.stats = nullptr;
+  p.N = N;
+  p.H = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;  // dout spatial size
+  p.W = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  if (p.H <= 0 || p.W <= 0) return SIHL_EARG;
+  p.Cin = Cout; p.Cout = Cin; p.KH = KH; p.KW = KW;
+  p.stride = 1; p.pad = pad_d_h; p.dil = dil;
+  p.Ho = H; p.Wo = W;
+  const long M = (long)N * H * W;
+  if (M > (1L << 30)) return SIHL_EARG;
+  p.M = (int)M;
+  p.act = SIHL_ACT_NONE; p.stats_mode = 0;
+  p.gridM = p.gridN = 0;
+  p.in_dilate = stride;
+  p.out_image_stride = (long)H * W * Cin;
   if (dtype == SIHL_F32) return dispatch<float>(p, stream);
   if (dtype == SIHL_BF16) return dispatch<bf16_t>(p, stream);
   return SIHL_EARG;

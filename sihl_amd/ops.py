@@ -253,10 +253,12 @@ class ConvBlockFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = conv2d_wgrad_raw(x, dz, KH, KW, stride, pad, dil).permute(0, 3, 1, 2)  # (O,I,KH,KW) view
         if ctx.needs_input_grad[0]:
-            if stride != 1:
-                raise NotImplementedError("input gradient of a strided convolution is not implemented yet")
             wt = weight_for_dgrad(w, flip=True)
-            dx, _ = conv2d_raw(dz, wt, None, 1, dil * (KH - 1) - pad, dil)
+            dx = torch.empty_like(x)
+            N, H, W, Cin = x.shape
+            rc = _C.lib().sihl_conv2d_dgrad(_p(dz), _p(wt), _p(dx), N, H, W, Cin, w.shape[0], KH, KW, stride, pad,
+                                            dil, _dt(x), _stream())
+            check(rc, "sihl_conv2d_dgrad")
         return dx, dw, dbias, dgamma, dbeta, None, None, None
 
 

@@ -182,7 +182,9 @@ _neck("fpn_3to5_eval", lambda ns: perturb_(ns.FPN(list(_BIFPN_CH), 32, 3, 5), 11
       _BIFPN_CH, 128, range(3, 6), 2, False, 70, [3, 4, 5])
 _neck("fpn_3to7_eval", lambda ns: perturb_(ns.FPN(list(_BIFPN_CH), 32, 3, 7), 12),
       _BIFPN_CH, 256, range(3, 6), 2, False, 80, [3, 4, 5, 6, 7])
-for c in ("fpn_3to5_train", "fpn_3to5_eval", "fpn_3to7_eval"):
+_neck("fpn_3to7_train", lambda ns: perturb_(ns.FPN(list(_BIFPN_CH), 32, 3, 7), 12),
+      _BIFPN_CH, 256, range(3, 6), 2, True, 80, [3, 4, 5, 6, 7])
+for c in ("fpn_3to5_train", "fpn_3to5_eval", "fpn_3to7_eval", "fpn_3to7_train"):
     CASES[c].needs = "fpn"
 
 

@@ -29,6 +29,8 @@ CONV_SHAPES = [
     (2, 1, 1, 32, 32, 3, 1, 1),
     (2, 16, 16, 96, 160, 3, 1, 1),   # ragged channel chunks / Cout tiles
     (2, 16, 16, 32, 32, 3, 2, 1),    # stride 2 (FPN extra levels)
+    (2, 15, 17, 32, 64, 3, 2, 1),    # stride 2, odd sizes
+    (2, 16, 16, 64, 32, 1, 2, 0),    # 1x1 stride 2 (ResNet downsample)
     (1, 1, 300, 256, 8, 1, 1, 0),    # linear head as 1x1 over rows
     (4, 64, 64, 256, 256, 3, 1, 1),  # a real L3-like tile count
 ]
@@ -65,10 +67,13 @@ def test_conv_fwd_wgrad_dgrad(shape, dtype, rtol, atol):
     F.conv2d(xr, wr, None, stride=s, padding=p).backward(dyq)
     dw = ops.conv2d_wgrad_raw(xd, dyd, K, K, s, p, 1)
     _close(dw.permute(0, 3, 1, 2), wr.grad, rtol, atol, "wgrad")
-    if s == 1:
-        wt = ops.weight_for_dgrad(wd, flip=True)
-        dx, _ = ops.conv2d_raw(dyd, wt, None, 1, K - 1 - p, 1)
-        _close(dx.permute(0, 3, 1, 2), xr.grad, rtol, atol, "dgrad")
+    from sihl_amd import _C
+    wt = ops.weight_for_dgrad(wd, flip=True)
+    dx = torch.empty_like(xd)
+    rc = _C.lib().sihl_conv2d_dgrad(ops._p(dyd), ops._p(wt), ops._p(dx), N, H, W, Cin, Cout, K, K, s, p, 1,
+                                    ops._dt(xd), ops._stream())
+    assert rc == 0
+    _close(dx.permute(0, 3, 1, 2), xr.grad, rtol, atol, "dgrad")
 
 
 @pytest.mark.parametrize("dtype,rtol,atol", DTYPES)
