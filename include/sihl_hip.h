@@ -47,6 +47,13 @@ extern "C" {
  * 0 = dense) lets the head's laterals write into a slice of the flat (B, P, C) position buffer
  * (object_detection.py:102-105).  Cout is unconstrained; Cin % vector == 0. */
 int sihl_conv2d_stat_rows(long M);
+/* Test hook: the conv has two loaders, LDS-DMA (default) and register-staged (used for >= 4 GiB tensors);
+ * on != 0 forces the register-staged one so that both stay parity-tested. */
+int sihl_conv2d_force_register_staging(int on);
+/* Tuning hook: pixel-tile size of the LDS-DMA kernel for Cout > 128 (0 = heuristic, 128 or 256). */
+int sihl_conv2d_tile_override(int bm);
+/* Tuning ablation of the LDS-DMA kernel (results are INVALID when non-zero): 1 = no in-loop DMA, 2 = no ds_read/MFMA. */
+int sihl_conv2d_debug(int mode);
 int sihl_conv2d_fwd(const void* in, const void* wt, const float* bias, void* out, int N, int H, int W, int Cin,
                     int Cout, int KH, int KW, int stride, int pad, int dil, int dtype, int act,
                     const float* pre_scale, const float* pre_shift, const float* post_scale,

@@ -19,6 +19,9 @@ P, I, L, F = c_void_p, c_int, c_long, c_float
 # name -> (restype, argtypes); order is exactly the C prototype in include/sihl_hip.h
 SIGNATURES = {
     "sihl_conv2d_stat_rows": (I, [L]),
+    "sihl_conv2d_force_register_staging": (I, [I]),
+    "sihl_conv2d_tile_override": (I, [I]),
+    "sihl_conv2d_debug": (I, [I]),
     "sihl_conv2d_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, P, P, P, I, P, L, L, P]),
     "sihl_conv2d_dgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "sihl_conv2d_wgrad_ws_bytes": (L, [I, I, I, I, I, I, I, I, I, I, I]),

@@ -36,11 +36,16 @@ struct ConvParams {
   int M;
   int act, stats_mode;  // stats_mode: 0 none, 1 after bias (pre-affine), 2 after activation
   long out_image_stride;  // elements between consecutive images of the output (>= Ho*Wo*Cout)
+  int dbg;                // tuning ablation: 1 = no DMA inside the loop, 2 = no MFMA/ds_read (results invalid)
   int in_dilate;          // >1: the input is read as if zero-dilated by this factor (dgrad of a strided conv)
   int gridM, gridN;
 };
 
-constexpr int BM = 128;
+bool g_force_reg = false;  // test hook: use the register-staged loader
+int g_dbg = 0;
+int g_tile_override = 0;    // test / tuning hook: 0 = heuristic, 128 / 256 = force that pixel-tile size
+
+constexpr int BM128 = 128;
 constexpr int KCB = 128;         // bytes of K per stage per row
 constexpr int LDS_STRIDE = 144;  // padded row (bytes)
 
@@ -56,14 +61,124 @@ template <> __device__ __forceinline__ void mma_step<float>(f32x16_t& c, const u
   c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
 }
 
+// Shared epilogue: bias -> [stats] -> pre-affine -> act -> [stats] -> post-affine, LDS transpose, row stores.
+// ACT and STATS are compile-time inside the element loop (a runtime switch there costs an expf per element).
+template <typename T, int BM, int BN, int WM, int WN, int ACT, int STATS>
+__device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32],
+                                                   char* smem, int tile_m, int m0, int n0) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int NTHREADS = WM * WN * 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NT = WTN / 32;
+  constexpr int EPI_STRIDE = BN * (int)sizeof(T) + 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  char* epi = smem;
+  float* red = (float*)(smem + BM * EPI_STRIDE);  // [2][WM][BN]
+  const int half = lane >> 5;
+  const bool has_pre = p.pre_scale != nullptr, has_post = p.post_scale != nullptr;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int cl = wn * WTN + j * 32 + (lane & 31);  // column inside the tile
+    const int co = n0 + cl;
+    const bool cok = co < p.Cout;
+    const float bias = (p.bias && cok) ? p.bias[co] : 0.f;
+    const float s1 = (has_pre && cok) ? p.pre_scale[co] : 1.f;
+    const float t1 = (has_pre && p.pre_shift && cok) ? p.pre_shift[co] : 0.f;
+    const float s2 = (has_post && cok) ? p.post_scale[co] : 1.f;
+    const float t2 = (has_post && p.post_shift && cok) ? p.post_shift[co] : 0.f;
+    float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = acc[i][j][r] + bias;
+        if (STATS == 1) { const float m = (m0 + row) < p.M ? v : 0.f; ssum += m; ssq += m * m; }
+        v = v * s1 + t1;
+        if (ACT == SIHL_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (ACT == SIHL_ACT_SILU) v = v / (1.f + expf(-v));
+        else if (ACT == SIHL_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+        if (STATS == 2) { const float m = (m0 + row) < p.M ? v : 0.f; ssum += m; ssq += m * m; }
+        v = v * s2 + t2;
+        elem<T>::st((T*)(epi + row * EPI_STRIDE) + cl, v);
+      }
+    }
+    if (STATS) {
+      ssum += __shfl_xor(ssum, 32);
+      ssq += __shfl_xor(ssq, 32);
+      if (half == 0) {
+        red[(0 * WM + wm) * BN + cl] = ssum;
+        red[(1 * WM + wm) * BN + cl] = ssq;
+      }
+    }
+  }
+  __syncthreads();
+  if (STATS) {
+    // one partial row per 128-pixel sub-tile, whatever BM is: row = tile_m * (BM/128) + half
+    constexpr int HALVES = BM / 128, WPH = WM / HALVES;  // waves (along M) per 128-pixel half
+    const int nrows = (p.M + 127) / 128;
+    for (int idx = tid; idx < BN * HALVES; idx += NTHREADS) {
+      const int c = idx % BN, hf = idx / BN;
+      const int co = n0 + c, srow = tile_m * HALVES + hf;
+      if (co < p.Cout && srow < nrows) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPH; ++w) {
+          s += red[(0 * WM + hf * WPH + w) * BN + c];
+          q += red[(1 * WM + hf * WPH + w) * BN + c];
+        }
+        p.stats[((long)srow * 2 + 0) * p.Cout + co] = s;
+        p.stats[((long)srow * 2 + 1) * p.Cout + co] = q;
+      }
+    }
+  }
+  // row-contiguous 16-byte stores
+  T* __restrict__ out = (T*)p.out;
+  constexpr int CHUNKS = BN * (int)sizeof(T) / 16;  // 16-byte chunks per tile row
+  const bool vec_ok = (p.Cout % VEC) == 0;
+  const int hw_o = p.Ho * p.Wo;
+  for (int idx = tid; idx < BM * CHUNKS; idx += NTHREADS) {
+    const int row = idx / CHUNKS, ch = idx - row * CHUNKS;
+    const int m = m0 + row, co = n0 + ch * VEC;
+    if (m >= p.M || co >= p.Cout) continue;
+    const char* src = epi + row * EPI_STRIDE + ch * 16;
+    const int n_img = m / hw_o;
+    T* dst = out + (long)n_img * p.out_image_stride + (long)(m - n_img * hw_o) * p.Cout + co;
+    if (vec_ok && co + VEC <= p.Cout) {
+      *(uint4*)dst = *(const uint4*)src;
+    } else {
+      for (int e = 0; e < VEC && co + e < p.Cout; ++e) dst[e] = ((const T*)src)[e];
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], char* smem,
+                                              int tile_m, int m0, int n0) {
+  // the combinations the hot path uses get their own straight-line body; the rest share the generic ones
+  if (p.stats_mode == 0) {
+    if (p.act == SIHL_ACT_NONE) conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_NONE, 0>(p, acc, smem, tile_m, m0, n0);
+    else if (p.act == SIHL_ACT_RELU) conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_RELU, 0>(p, acc, smem, tile_m, m0, n0);
+    else if (p.act == SIHL_ACT_SILU) conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_SILU, 0>(p, acc, smem, tile_m, m0, n0);
+    else conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_SIGMOID, 0>(p, acc, smem, tile_m, m0, n0);
+  } else if (p.stats_mode == 1) {
+    conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_NONE, 1>(p, acc, smem, tile_m, m0, n0);  // conv -> BN -> act
+  } else {
+    if (p.act == SIHL_ACT_RELU) conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_RELU, 2>(p, acc, smem, tile_m, m0, n0);
+    else if (p.act == SIHL_ACT_NONE) conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_NONE, 2>(p, acc, smem, tile_m, m0, n0);
+    else if (p.act == SIHL_ACT_SILU) conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_SILU, 2>(p, acc, smem, tile_m, m0, n0);
+    else conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_SIGMOID, 2>(p, acc, smem, tile_m, m0, n0);
+  }
+}
+
 template <typename T, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+  constexpr int BM = BM128;
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int KCE = KCB / (int)sizeof(T);
   constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NT = WTN / 32;
   constexpr int A_BYTES = BM * LDS_STRIDE, B_BYTES = BN * LDS_STRIDE, STAGE = A_BYTES + B_BYTES;
   constexpr int NB = BN / 32;  // weight rows per loader thread
-  constexpr int EPI_STRIDE = BN * (int)sizeof(T) + 16;
   static_assert(WM * WN == 4, "4 waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -177,85 +292,287 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue (all staging LDS is free now)
-  char* epi = smem;
-  float* red = (float*)(smem + BM * EPI_STRIDE);  // [2][WM][BN]
-  const int half = lane >> 5;
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int cl = wn * WTN + j * 32 + (lane & 31);  // column inside the tile
-    const int co = n0 + cl;
-    const bool cok = co < p.Cout;
-    const float bias = (p.bias && cok) ? p.bias[co] : 0.f;
-    const float s1 = (p.pre_scale && cok) ? p.pre_scale[co] : 1.f;
-    const float t1 = (p.pre_shift && cok) ? p.pre_shift[co] : 0.f;
-    const float s2 = (p.post_scale && cok) ? p.post_scale[co] : 1.f;
-    const float t2 = (p.post_shift && cok) ? p.post_shift[co] : 0.f;
-    float ssum = 0.f, ssq = 0.f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const bool rok = (m0 + row) < p.M;
-        float v = acc[i][j][r] + bias;
-        if (p.stats_mode == 1 && rok) { ssum += v; ssq += v * v; }
-        v = v * s1 + t1;
-        v = apply_act(v, p.act);
-        if (p.stats_mode == 2 && rok) { ssum += v; ssq += v * v; }
-        v = v * s2 + t2;
-        elem<T>::st((T*)(epi + row * EPI_STRIDE) + cl, v);
-      }
-    }
-    if (p.stats_mode) {
-      ssum += __shfl_xor(ssum, 32);
-      ssq += __shfl_xor(ssq, 32);
-      if (half == 0) {
-        red[(0 * WM + wm) * BN + cl] = ssum;
-        red[(1 * WM + wm) * BN + cl] = ssq;
-      }
-    }
-  }
-  __syncthreads();
-  if (p.stats_mode) {
-    for (int c = tid; c < BN; c += 256) {
-      const int co = n0 + c;
-      if (co < p.Cout) {
-        float s = 0.f, q = 0.f;
-#pragma unroll
-        for (int w = 0; w < WM; ++w) { s += red[(0 * WM + w) * BN + c]; q += red[(1 * WM + w) * BN + c]; }
-        p.stats[((long)tile_m * 2 + 0) * p.Cout + co] = s;
-        p.stats[((long)tile_m * 2 + 1) * p.Cout + co] = q;
-      }
-    }
-  }
-  // row-contiguous 16-byte stores
-  T* __restrict__ out = (T*)p.out;
-  constexpr int CHUNKS = BN * (int)sizeof(T) / 16;  // 16-byte chunks per tile row
-  const bool vec_ok = (p.Cout % VEC) == 0;
-  for (int idx = tid; idx < BM * CHUNKS; idx += 256) {
-    const int row = idx / CHUNKS, ch = idx - row * CHUNKS;
-    const int m = m0 + row, co = n0 + ch * VEC;
-    if (m >= p.M || co >= p.Cout) continue;
-    const char* src = epi + row * EPI_STRIDE + ch * 16;
-    const int hw_o = p.Ho * p.Wo, n_img = m / hw_o;
-    T* dst = out + (long)n_img * p.out_image_stride + (long)(m - n_img * hw_o) * p.Cout + co;
-    if (vec_ok && co + VEC <= p.Cout) {
-      *(uint4*)dst = *(const uint4*)src;
-    } else {
-      for (int e = 0; e < VEC && co + e < p.Cout; ++e) dst[e] = ((const T*)src)[e];
-    }
-  }
+  conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, tile_m, m0, n0);
 }
 
-template <typename T, int BN, int WM, int WN>
-int launch(const ConvParams& p0, hipStream_t stream) {
+// ---------------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the main loop (the default): tiles go global -> LDS directly with
+// buffer_load_dwordx4 ... lds (no VGPR staging, no ds_write pass).  One wave-instruction writes 1 KiB of LDS
+// linearly = 8 rows x 128 B, so rows are unpadded and bank conflicts are removed by an XOR swizzle applied
+// on the SOURCE side: LDS position (row, pos) holds global 16-byte chunk  pos ^ ((row >> 1) & 7)  of that
+// row, and the fragment reads apply the same XOR (16 lanes of a ds_read_b128 group then hit 16 distinct
+// 4-bank slots).  Out-of-image taps, rows beyond M, channels beyond Cin and weight rows beyond Cout are
+// given an out-of-range buffer offset: the hardware bounds check returns zeros, which land in LDS.
+constexpr unsigned OOB = 0xFFFFFFF0u;
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+// Raw buffer descriptor (base, stride 0, num_records bytes, raw 32-bit format) from wave-uniform values.
+__device__ __forceinline__ v4i_t make_rsrc(const void* ptr, unsigned bytes) {
+  const unsigned long a = (unsigned long)ptr;
+  v4i_t r;
+  r[0] = (int)(unsigned)a;
+  r[1] = (int)((unsigned)(a >> 32) & 0xffffu);
+  r[2] = (int)bytes;
+  r[3] = 0x00020000;
+  return r;
+}
+
+// One LDS-DMA wave-instruction: 64 lanes x 16 B -> 1 KiB of LDS at the wave-uniform byte address lds_dst.
+// Issued through inline asm ON PURPOSE: hipcc would otherwise put s_waitcnt vmcnt(0) in front of the next
+// ds_read (it cannot tell that the DMA targets the OTHER stage buffer) and serialise DMA with MFMA.  The
+// main loop therefore waits for the DMA itself (s_waitcnt vmcnt(0) before the barrier that publishes the
+// stage).  M0 (the LDS-DMA destination base) is written in the same statement that reads it; nothing else in
+// these kernels uses M0 (gfx9 ds_* instructions do not).
+__device__ __forceinline__ void dma16(unsigned voff, unsigned lds_dst, v4i_t rsrc) {
+  asm volatile(
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %0, %2, 0 offen lds"
+      :
+      : "v"(voff), "s"(lds_dst), "s"(rsrc)
+      : "memory");
+}
+
+// DIL: strided-dgrad instantiation (input read as if zero-dilated); the common case compiles without it.
+template <typename T, int BM, int BN, int WM, int WN, bool DIL>
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(const ConvParams p) {
+  constexpr int NTHREADS = WM * WN * 64;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int KCE = KCB / (int)sizeof(T);
+  constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NT = WTN / 32;
+  constexpr int A_BYTES = BM * KCB, B_BYTES = BN * KCB, STAGE = A_BYTES + B_BYTES;
+  constexpr int NA = BM * 8 / NTHREADS, NBL = BN * 8 / NTHREADS;  // 16-byte slots per thread per stage
+  constexpr int NKS = KCB / 32;                                    // k-steps per stage
+  static_assert(NA >= 1 && NBL >= 1, "tile too small for the thread count");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int L = xcd_remap(blockIdx.x, p.gridM * p.gridN);
+  const int tile_m = L / p.gridN, tile_n = L % p.gridN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int ntaps = p.KH * p.KW;
+  const int nchunks = (p.Cin + KCE - 1) / KCE;
+  const int nstages = nchunks * ntaps;
+
+  const v4i_t in_rsrc = make_rsrc(p.in, (unsigned)((long)p.N * p.H * p.W * p.Cin * (long)sizeof(T)));
+  const v4i_t wt_rsrc = make_rsrc(p.wt, (unsigned)((long)p.Cout * ntaps * p.Cin * (long)sizeof(T)));
+  const unsigned lds_base = (unsigned)(unsigned long)(lds_ptr_t)smem;
+
+  // ---- per-thread slot geometry (fixed for the whole K loop).  Per K stage only a scalar delta is added:
+  //   voff = slot_offset + tap_delta(ky,kx) + kc*128      valid iff bit `tap` of the slot's tap mask is set
+  // (the mask folds image borders and rows beyond M; tensors are < 2 GiB, so 0x80000000 + anything is
+  // out of range for the buffer bounds check and comes back as zeros).
+  unsigned a_off[NA], a_mask[NA];
+  int a_ch[NA];
+  int a_iy0[NA], a_ix0[NA];  // DIL only
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int q = (wave * NA + j) * 64 + lane, row = q >> 3, pos = q & 7;
+    a_ch[j] = (pos ^ ((row >> 1) & 7)) * VEC;
+    const int m = m0 + row;
+    a_off[j] = 0;
+    a_mask[j] = 0;
+    a_iy0[j] = a_ix0[j] = 0;
+    if (m < p.M) {
+      const int hw = p.Ho * p.Wo;
+      const int n = m / hw, r = m - n * hw;
+      const int oy = r / p.Wo, ox = r - oy * p.Wo;
+      const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+      a_iy0[j] = iy0;
+      a_ix0[j] = ix0;
+      int t = 0;
+      for (int ky = 0; ky < p.KH; ++ky) {
+        for (int kx = 0; kx < p.KW; ++kx, ++t) {
+          int iy = iy0 + ky * p.dil, ix = ix0 + kx * p.dil;
+          bool ok = iy >= 0 && ix >= 0;
+          if (DIL) {
+            ok = ok && (iy % p.in_dilate == 0) && (ix % p.in_dilate == 0);
+            iy /= p.in_dilate;
+            ix /= p.in_dilate;
+          }
+          if (ok && iy < p.H && ix < p.W) a_mask[j] |= 1u << t;
+        }
+      }
+      const long pix0 = DIL ? 0 : ((long)iy0 * p.W + ix0);
+      a_off[j] = (unsigned)(((long)n * p.H * p.W * p.Cin + pix0 * p.Cin + a_ch[j]) * (long)sizeof(T));
+    }
+  }
+  unsigned b_off[NBL];
+  int b_ch[NBL];
+#pragma unroll
+  for (int j = 0; j < NBL; ++j) {
+    const int q = (wave * NBL + j) * 64 + lane, row = q >> 3, pos = q & 7;
+    b_ch[j] = (pos ^ ((row >> 1) & 7)) * VEC;
+    const int co = n0 + row;
+    b_off[j] = co < p.Cout ? (unsigned)(((long)co * ntaps * p.Cin + b_ch[j]) * (long)sizeof(T)) : 0x80000000u;
+  }
+  const bool cin_full = (p.Cin % KCE) == 0;
+
+  // scalar state of the stage being prefetched
+  int n_kc = 0, n_tap = 0, n_adelta = 0, n_bdelta = 0, n_ky = 0, n_kx = 0;
+  unsigned n_abase = 0, n_bbase = 0, n_tapbit = 1;
+  auto stage_setup = [&](int s, int buf) {
+    n_kc = s / ntaps;
+    n_tap = s - n_kc * ntaps;
+    n_ky = n_tap / p.KW;
+    n_kx = n_tap - n_ky * p.KW;
+    n_tapbit = 1u << n_tap;
+    n_adelta = ((n_ky * p.dil * p.W + n_kx * p.dil) * p.Cin) * (int)sizeof(T) + n_kc * KCB;
+    n_bdelta = n_tap * p.Cin * (int)sizeof(T) + n_kc * KCB;
+    n_abase = lds_base + buf * STAGE + wave * NA * 1024;
+    n_bbase = lds_base + buf * STAGE + A_BYTES + wave * NBL * 1024;
+  };
+  auto issue_a = [&](int j) {
+    bool ok = (a_mask[j] & n_tapbit) != 0;
+    if (!cin_full) ok = ok && (n_kc * KCE + a_ch[j] < p.Cin);
+    unsigned voff;
+    if (!DIL) {
+      voff = a_off[j] + (unsigned)n_adelta;
+    } else {
+      const int iy = (a_iy0[j] + n_ky * p.dil) / p.in_dilate, ix = (a_ix0[j] + n_kx * p.dil) / p.in_dilate;
+      voff = a_off[j] + (unsigned)(((iy * p.W + ix) * p.Cin) * (int)sizeof(T) + n_kc * KCB);
+    }
+    dma16(ok ? voff : OOB, n_abase + j * 1024, in_rsrc);
+  };
+  auto issue_b = [&](int j) {
+    unsigned voff = b_off[j] + (unsigned)n_bdelta;
+    if (!cin_full) voff = (n_kc * KCE + b_ch[j] < p.Cin) ? voff : OOB;
+    dma16(voff, n_bbase + j * 1024, wt_rsrc);
+  };
+
+  f32x16_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
+  int koff[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) koff[ks] = fr * KCB + (((ks * 2 + fh) ^ fsw) << 4);
+
+  stage_setup(0, 0);
+#pragma unroll
+  for (int j = 0; j < NA; ++j) issue_a(j);
+#pragma unroll
+  for (int j = 0; j < NBL; ++j) issue_b(j);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int s = 0; s < nstages; ++s) {
+    const bool more = (s + 1 < nstages) && !(p.dbg & 1);
+    if (more) stage_setup(s + 1, (s + 1) & 1);
+    const char* As = smem + (s & 1) * STAGE + wm * WTM * KCB;
+    const char* Bs = smem + (s & 1) * STAGE + A_BYTES + wn * WTN * KCB;
+    // DMA issue schedule for the next stage (p.dbg bits 2-3 select it while tuning):
+    //   0: NA/NBL slots spread over the k-steps   1: everything before the first k-step
+    //   2: staggered - waves of the first half issue before k-step 0, the others after k-step 1
+    //   3: front-loaded - slots spread over the first half of the k-steps
+    const int sched = (p.dbg & 16) ? ((p.dbg >> 2) & 3) : (BM >= 256 ? 3 : 1);
+    const bool early = sched == 1 || (sched == 2 && wave < WM * WN / 2);
+    if (!(p.dbg & 2)) {
+      uint4 fa[2][MT], fb[2][NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fa[0][i] = *(const uint4*)(As + i * 32 * KCB + koff[0]);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fb[0][j] = *(const uint4*)(Bs + j * 32 * KCB + koff[0]);
+      if (more && early) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) issue_a(j);
+#pragma unroll
+        for (int j = 0; j < NBL; ++j) issue_b(j);
+      }
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        if (ks + 1 < NKS) {  // fragments of the next k-step are in flight while this one multiplies
+#pragma unroll
+          for (int i = 0; i < MT; ++i) fa[(ks + 1) & 1][i] = *(const uint4*)(As + i * 32 * KCB + koff[ks + 1]);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) fb[(ks + 1) & 1][j] = *(const uint4*)(Bs + j * 32 * KCB + koff[ks + 1]);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) mma_step<T>(acc[i][j], fa[ks & 1][i], fb[ks & 1][j]);
+        if (more && !early) {
+          if (sched == 0) {
+#pragma unroll
+            for (int j = ks; j < NA; j += NKS) issue_a(j);
+#pragma unroll
+            for (int j = ks; j < NBL; j += NKS) issue_b(j);
+          } else if (sched == 2) {
+            if (ks == 1) {
+#pragma unroll
+              for (int j = 0; j < NA; ++j) issue_a(j);
+#pragma unroll
+              for (int j = 0; j < NBL; ++j) issue_b(j);
+            }
+          } else if (ks < NKS / 2) {
+#pragma unroll
+            for (int j = ks; j < NA; j += NKS / 2) issue_a(j);
+#pragma unroll
+            for (int j = ks; j < NBL; j += NKS / 2) issue_b(j);
+          }
+        }
+      }
+    } else if (more) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) issue_a(j);
+#pragma unroll
+      for (int j = 0; j < NBL; ++j) issue_b(j);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed ...
+    __syncthreads();                                   // ... and so have everybody else's
+  }
+  if (p.dbg & 32) return;  // tuning ablation: no epilogue
+  conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, tile_m, m0, n0);
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_dma(const ConvParams& p0, hipStream_t stream) {
   ConvParams p = p0;
   p.gridM = (p.M + BM - 1) / BM;
   p.gridN = (p.Cout + BN - 1) / BN;
-  constexpr int STAGE = (BM + BN) * LDS_STRIDE;
   constexpr int EPI = BM * (BN * (int)sizeof(T) + 16) + 2 * WM * BN * 4;
-  constexpr int LDS = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
+  constexpr int STAGES2 = 2 * (BM + BN) * KCB;
+  constexpr int LDS = STAGES2 > EPI ? STAGES2 : EPI;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  auto kern = p.in_dilate > 1 ? conv_igemm_dma_kernel<T, BM, BN, WM, WN, true>
+                              : conv_igemm_dma_kernel<T, BM, BN, WM, WN, false>;
+  if (!attr_set) {
+    hipError_t e0 = hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<T, BM, BN, WM, WN, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e0 != hipSuccess) return (int)e0;
+    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<T, BM, BN, WM, WN, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const double flops = 2.0 * p.M * (double)p.Cout * p.KH * p.KW * p.Cin;
+  const double bytes = ((double)p.N * p.H * p.W * p.Cin + (double)p.M * p.Cout + (double)p.Cout * p.KH * p.KW * p.Cin) * sizeof(T);
+  sihl_prof_begin(SIHL_PROF_CONV, sizeof(T) == 2 ? SIHL_BF16 : SIHL_F32, flops, bytes, stream);
+  hipLaunchKernelGGL(kern, dim3(p.gridM * p.gridN), dim3(WM * WN * 64), LDS, stream, p);
+  sihl_prof_end(stream);
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+template <typename T, int BN, int WM, int WN>
+int launch_reg(const ConvParams& p0, hipStream_t stream) {
+  ConvParams p = p0;
+  constexpr int BM = BM128;
+  p.gridM = (p.M + BM - 1) / BM;
+  p.gridN = (p.Cout + BN - 1) / BN;
+  constexpr int EPI = BM * (BN * (int)sizeof(T) + 16) + 2 * WM * BN * 4;
+  constexpr int STAGES2 = 2 * (BM + BN) * LDS_STRIDE;
+  constexpr int LDS = STAGES2 > EPI ? STAGES2 : EPI;
   static bool attr_set = false;
   auto kern = conv_igemm_kernel<T, BN, WM, WN>;
   if (!attr_set) {
@@ -276,17 +593,42 @@ template <typename T>
 int dispatch(const ConvParams& p, hipStream_t stream) {
   constexpr int VEC = 16 / (int)sizeof(T);
   if (p.Cin % VEC != 0) return SIHL_EARG;  // 16-byte channel vectors required; caller pads
-  if (p.Cout > 128) return launch<T, 256, 2, 2>(p, stream);
-  if (p.Cout > 64) return launch<T, 128, 2, 2>(p, stream);
-  return launch<T, 64, 4, 1>(p, stream);
+  const long in_bytes = (long)p.N * p.H * p.W * p.Cin * (long)sizeof(T);
+  const long wt_bytes = (long)p.Cout * p.KH * p.KW * p.Cin * (long)sizeof(T);
+  const bool dma = !g_force_reg && in_bytes < (1L << 31) && wt_bytes < (1L << 31) && p.KH * p.KW <= 32;
+  if (!dma) {
+    if (p.Cout > 128) return launch_reg<T, 256, 2, 2>(p, stream);
+    if (p.Cout > 64) return launch_reg<T, 128, 2, 2>(p, stream);
+    return launch_reg<T, 64, 4, 1>(p, stream);
+  }
+  if (p.Cout > 128) {
+    // 256-pixel x 256-channel tiles (8 waves) halve the weight-panel traffic per flop; worth it once the
+    // grid still fills the chip
+    if constexpr (sizeof(T) == 2) {
+      if (g_tile_override == 256 || (g_tile_override == 0 && p.M >= 256 * 256))
+        return launch_dma<T, 256, 256, 4, 2>(p, stream);
+    }
+    return launch_dma<T, 128, 256, 2, 2>(p, stream);
+  }
+  if (p.Cout > 64) return launch_dma<T, 128, 128, 2, 2>(p, stream);
+  return launch_dma<T, 128, 64, 4, 1>(p, stream);
 }
 
 }  // namespace
 
 extern "C" {
 
-// Number of (sum, sumsq) partial rows the conv writes for M output pixels.
-int sihl_conv2d_stat_rows(long M) { return (int)((M + BM - 1) / BM); }
+// Test hook: 1 = use the register-staged loader instead of LDS-DMA (both are kept parity-tested).
+int sihl_conv2d_force_register_staging(int on) { g_force_reg = on != 0; return 0; }
+
+// Tuning ablation (results invalid when non-zero): 1 = skip the in-loop DMA, 2 = skip ds_read/MFMA.
+int sihl_conv2d_debug(int mode) { g_dbg = mode; return 0; }
+
+// Tuning hook: force the pixel-tile size of the LDS-DMA kernel (0 = heuristic, 128, 256).
+int sihl_conv2d_tile_override(int bm) { g_tile_override = bm; return 0; }
+
+// Number of (sum, sumsq) partial rows the conv may write for M output pixels (upper bound over tile sizes).
+int sihl_conv2d_stat_rows(long M) { return (int)((M + BM128 - 1) / BM128); }
 
 int sihl_conv2d_fwd(const void* in, const void* wt, const float* bias, void* out, int N, int H, int W, int Cin,
                     int Cout, int KH, int KW, int stride, int pad, int dil, int dtype, int act,
@@ -311,9 +653,11 @@ int sihl_conv2d_fwd(const void* in, const void* wt, const float* bias, void* out
   p.act = act; p.stats_mode = stats_mode;
   p.gridM = p.gridN = 0;
   p.in_dilate = 1;
+  p.dbg = g_dbg;
   p.out_image_stride = out_image_stride > 0 ? out_image_stride : (long)p.Ho * p.Wo * Cout;
   if (p.out_image_stride < (long)p.Ho * p.Wo * Cout) return SIHL_EARG;
   if (p.out_image_stride % (dtype == SIHL_BF16 ? 8 : 4)) return SIHL_EARG;
+  if (stats_mode == 1 && act != SIHL_ACT_NONE) return SIHL_EARG;  // pre-norm statistics are taken with no activation
   if (stats_mode) {
     if (!stats_ws) return SIHL_EARG;
     if (stats_ws_bytes < (long)sihl_conv2d_stat_rows(M) * 2 * Cout * (long)sizeof(float)) return SIHL_EWS;
@@ -349,6 +693,7 @@ int sihl_conv2d_dgrad(const void* dout, const void* wt_t, void* din, int N, int 
   p.act = SIHL_ACT_NONE; p.stats_mode = 0;
   p.gridM = p.gridN = 0;
   p.in_dilate = stride;
+  p.dbg = 0;
   p.out_image_stride = (long)H * W * Cin;
   if (dtype == SIHL_F32) return dispatch<float>(p, stream);
   if (dtype == SIHL_BF16) return dispatch<bf16_t>(p, stream);

@@ -36,9 +36,19 @@ CONV_SHAPES = [
 ]
 
 
+@pytest.fixture(params=["lds_dma", "lds_dma_bm256", "register_staged"])
+def loader(request):
+    from sihl_amd import _C
+    _C.lib().sihl_conv2d_force_register_staging(int(request.param == "register_staged"))
+    _C.lib().sihl_conv2d_tile_override(256 if request.param == "lds_dma_bm256" else 0)
+    yield request.param
+    _C.lib().sihl_conv2d_force_register_staging(0)
+    _C.lib().sihl_conv2d_tile_override(0)
+
+
 @pytest.mark.parametrize("dtype,rtol,atol", DTYPES)
 @pytest.mark.parametrize("shape", CONV_SHAPES)
-def test_conv_fwd_wgrad_dgrad(shape, dtype, rtol, atol):
+def test_conv_fwd_wgrad_dgrad(shape, dtype, rtol, atol, loader):
     ops = _ops()
     N, H, W, Cin, Cout, K, s, p = shape
     g = torch.Generator().manual_seed(0)
