@@ -96,41 +96,69 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
 }
 
 // ------------------------------------------------------------------ y = act(x*scale[c] + shift[c])
-template <typename T>
+template <int ACT> __device__ __forceinline__ float act_c(float v) {
+  if (ACT == SIHL_ACT_RELU) return fmaxf(v, 0.f);
+  if (ACT == SIHL_ACT_SILU) return v / (1.f + expf(-v));
+  if (ACT == SIHL_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+  return v;
+}
+template <int ACT> __device__ __forceinline__ float act_grad_c(float v) {
+  if (ACT == SIHL_ACT_RELU) return v > 0.f ? 1.f : 0.f;
+  if (ACT == SIHL_ACT_SILU) { const float s = 1.f / (1.f + expf(-v)); return s * (1.f + v * (1.f - s)); }
+  if (ACT == SIHL_ACT_SIGMOID) { const float s = 1.f / (1.f + expf(-v)); return s * (1.f - s); }
+  return 1.f;
+}
+
+// The launchers pick a grid whose total thread count is a multiple of cvec whenever cvec divides it, so a thread
+// always meets the same channel vector and keeps its scale/shift in registers (FIXED = true).
+template <typename T, int ACT, bool FIXED>
 __global__ void affine_act_kernel(const T* __restrict__ x, T* __restrict__ y, long nvec, int cvec,
-                                  const float* __restrict__ scale, const float* __restrict__ shift, int act) {
+                                  const float* __restrict__ scale, const float* __restrict__ shift) {
   constexpr int V = 16 / sizeof(T);
-  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
-    const int c = (int)(i % cvec) * V;
+  float sc[V], sh[V];
+  const long i0 = (long)blockIdx.x * TPB + threadIdx.x;
+  if (FIXED) {
+    const int c = (int)(i0 % cvec) * V;
+#pragma unroll
+    for (int e = 0; e < V; ++e) { sc[e] = scale ? scale[c + e] : 1.f; sh[e] = (scale && shift) ? shift[c + e] : 0.f; }
+  }
+  for (long i = i0; i < nvec; i += (long)gridDim.x * TPB) {
+    if (!FIXED) {
+      const int c = (int)(i % cvec) * V;
+#pragma unroll
+      for (int e = 0; e < V; ++e) { sc[e] = scale ? scale[c + e] : 1.f; sh[e] = (scale && shift) ? shift[c + e] : 0.f; }
+    }
     float f[V];
     ldv(x + i * V, f);
 #pragma unroll
-    for (int e = 0; e < V; ++e) {
-      float v = f[e];
-      if (scale) v = v * scale[c + e] + (shift ? shift[c + e] : 0.f);
-      f[e] = apply_act(v, act);
-    }
+    for (int e = 0; e < V; ++e) f[e] = act_c<ACT>(f[e] * sc[e] + sh[e]);
     stv(y + i * V, f);
   }
 }
 
 // dx = dy * act'(x*scale+shift) * scale ; used for stand-alone activations (silu / sigmoid / relu)
-template <typename T>
+template <typename T, int ACT, bool FIXED>
 __global__ void affine_act_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, long nvec,
-                                      int cvec, const float* __restrict__ scale, const float* __restrict__ shift,
-                                      int act) {
+                                      int cvec, const float* __restrict__ scale, const float* __restrict__ shift) {
   constexpr int V = 16 / sizeof(T);
-  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
-    const int c = (int)(i % cvec) * V;
+  float sc[V], sh[V];
+  const long i0 = (long)blockIdx.x * TPB + threadIdx.x;
+  if (FIXED) {
+    const int c = (int)(i0 % cvec) * V;
+#pragma unroll
+    for (int e = 0; e < V; ++e) { sc[e] = scale ? scale[c + e] : 1.f; sh[e] = (scale && shift) ? shift[c + e] : 0.f; }
+  }
+  for (long i = i0; i < nvec; i += (long)gridDim.x * TPB) {
+    if (!FIXED) {
+      const int c = (int)(i % cvec) * V;
+#pragma unroll
+      for (int e = 0; e < V; ++e) { sc[e] = scale ? scale[c + e] : 1.f; sh[e] = (scale && shift) ? shift[c + e] : 0.f; }
+    }
     float f[V], g[V];
     ldv(x + i * V, f);
     ldv(dy + i * V, g);
 #pragma unroll
-    for (int e = 0; e < V; ++e) {
-      const float s = scale ? scale[c + e] : 1.f;
-      const float v = f[e] * s + (shift ? shift[c + e] : 0.f);
-      g[e] = g[e] * act_grad(v, act) * s;
-    }
+    for (int e = 0; e < V; ++e) g[e] = g[e] * act_grad_c<ACT>(f[e] * sc[e] + sh[e]) * sc[e];
     stv(dx + i * V, g);
   }
 }
@@ -699,31 +727,40 @@ __global__ void colsum_finalize_kernel(const float* __restrict__ part, int R, in
   if (ry == 0 && idx < KC) out[idx] = (float)(sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx]);
 }
 
-// dz for conv->act->BN (mode 0) or conv->BN->act (mode 1); batch_stats: include the mean/var terms
-template <typename T>
+// dz for conv->act->BN (MODE 0) or conv->BN->act (MODE 1); batch_stats: include the mean/var terms
+template <typename T, int MODE, int ACT, bool FIXED>
 __global__ void norm_bwd_apply_kernel(const T* __restrict__ s, const T* __restrict__ dy, T* __restrict__ dz, long nvec,
                                       int cvec, const float* __restrict__ mean, const float* __restrict__ rstd,
                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ sums /*[2][C]: dbeta, dgamma*/, float inv_count,
-                                      int mode, int act, int batch_stats) {
+                                      int batch_stats) {
   constexpr int V = 16 / sizeof(T);
   const int C = cvec * V;
-  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
-    const int c0 = (int)(i % cvec) * V;
+  float mu[V], rs[V], ga[V], be[V], k0[V], k1[V];
+  auto load_params = [&](int c0) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const int c = c0 + e;
+      mu[e] = mean[c]; rs[e] = rstd[c];
+      ga[e] = gamma ? gamma[c] : 1.f; be[e] = beta ? beta[c] : 0.f;
+      k0[e] = batch_stats ? inv_count * sums[c] : 0.f;
+      k1[e] = batch_stats ? inv_count * sums[C + c] : 0.f;
+    }
+  };
+  const long i0 = (long)blockIdx.x * TPB + threadIdx.x;
+  if (FIXED) load_params((int)(i0 % cvec) * V);
+  for (long i = i0; i < nvec; i += (long)gridDim.x * TPB) {
+    if (!FIXED) load_params((int)(i % cvec) * V);
     float fs[V], fd[V];
     ldv(s + i * V, fs);
     ldv(dy + i * V, fd);
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-      const int c = c0 + e;
-      const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-      const float xh = (fs[e] - mean[c]) * rstd[c];
+      const float xh = (fs[e] - mu[e]) * rs[e];
       float g = fd[e];
-      if (mode == 1) g *= act_grad(xh * ga + be, act);
-      float dr = g;
-      if (batch_stats) dr -= inv_count * (sums[c] + xh * sums[C + c]);
-      dr *= ga * rstd[c];
-      if (mode == 0) dr *= act_grad(fs[e], act);  // s is post-activation: relu mask from s > 0
+      if (MODE == 1) g *= act_grad_c<ACT>(xh * ga[e] + be[e]);
+      float dr = (g - k0[e] - xh * k1[e]) * ga[e] * rs[e];
+      if (MODE == 0) dr *= act_grad_c<ACT>(fs[e]);  // s is post-activation: relu mask from s > 0
       fd[e] = dr;
     }
     stv(dz + i * V, fd);
@@ -731,45 +768,62 @@ __global__ void norm_bwd_apply_kernel(const T* __restrict__ s, const T* __restri
 }
 
 // ------------------------------------------------------------------ LayerNorm + activation over rows of C
-// one wave per row; lane owns chunks lane, lane+64 (C <= 128*V)
-template <typename T>
+// SUB lanes cooperate on one row (64/SUB rows per wave); a lane owns 16-byte chunks sub and sub+SUB (C <= 2*SUB*V).
+template <int SUB> __device__ __forceinline__ float sub_sum(float v) {
+#pragma unroll
+  for (int o = SUB / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <typename T, int SUB, int ACT>
 __global__ void layernorm_act_kernel(const T* __restrict__ z, T* __restrict__ y, long rows, int C,
                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                     int act, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
-  constexpr int V = 16 / sizeof(T);
-  const int cvec = C / V, lane = threadIdx.x & 63;
+                                     float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  constexpr int V = 16 / sizeof(T), RPW = 64 / SUB;
+  const int cvec = C / V, lane = threadIdx.x & 63, sub = lane % SUB, rsel = lane / SUB;
   const long wave = ((long)blockIdx.x * TPB + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * TPB) >> 6;
-  for (long r = wave; r < rows; r += nwaves) {
+  float ga[2][V], be[2][V];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int cv = sub + SUB * k;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      ga[k][e] = cv < cvec ? gamma[cv * V + e] : 0.f;
+      be[k][e] = cv < cvec ? beta[cv * V + e] : 0.f;
+    }
+  }
+  for (long r0 = wave * RPW; r0 < rows; r0 += nwaves * RPW) {
+    const long r = r0 + rsel;
+    const bool rok = r < rows;
     float f[2][V];
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int cv = lane + 64 * k;
-      if (cv < cvec) {
+      const int cv = sub + SUB * k;
+#pragma unroll
+      for (int e = 0; e < V; ++e) f[k][e] = 0.f;
+      if (rok && cv < cvec) {
         ldv(z + (r * cvec + cv) * V, f[k]);
 #pragma unroll
         for (int e = 0; e < V; ++e) s += f[k][e];
       }
     }
-    const float mu = wave_sum(s) / C;
+    const float mu = sub_sum<SUB>(s) / C;
     float q = 0.f;
 #pragma unroll
     for (int k = 0; k < 2; ++k)
-      if (lane + 64 * k < cvec) {
+      if (sub + SUB * k < cvec) {
 #pragma unroll
         for (int e = 0; e < V; ++e) { const float d = f[k][e] - mu; q += d * d; }
       }
-    const float rs = 1.f / sqrtf(wave_sum(q) / C + eps);
-    if (lane == 0 && mean_out) { mean_out[r] = mu; rstd_out[r] = rs; }
+    const float rs = 1.f / sqrtf(sub_sum<SUB>(q) / C + eps);
+    if (rok && sub == 0 && mean_out) { mean_out[r] = mu; rstd_out[r] = rs; }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int cv = lane + 64 * k;
-      if (cv < cvec) {
+      const int cv = sub + SUB * k;
+      if (rok && cv < cvec) {
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-          const int c = cv * V + e;
-          f[k][e] = apply_act((f[k][e] - mu) * rs * gamma[c] + beta[c], act);
-        }
+        for (int e = 0; e < V; ++e) f[k][e] = act_c<ACT>((f[k][e] - mu) * rs * ga[k][e] + be[k][e]);
         stv(y + (r * cvec + cv) * V, f[k]);
       }
     }
@@ -778,50 +832,59 @@ __global__ void layernorm_act_kernel(const T* __restrict__ z, T* __restrict__ y,
 
 // dz = rstd * (gh - mean_c(gh) - xhat * mean_c(gh*xhat)), gh = dy*act'(u)*gamma ; per-wave column partials
 // part: [nwaves][2][C] (dbeta, dgamma)
-template <typename T>
+template <typename T, int SUB, int ACT>
 __global__ void layernorm_act_bwd_kernel(const T* __restrict__ z, const T* __restrict__ dy, T* __restrict__ dz,
                                          long rows, int C, const float* __restrict__ gamma,
                                          const float* __restrict__ beta, const float* __restrict__ mean,
-                                         const float* __restrict__ rstd, int act, float* __restrict__ part) {
-  constexpr int V = 16 / sizeof(T);
-  const int cvec = C / V, lane = threadIdx.x & 63;
+                                         const float* __restrict__ rstd, float* __restrict__ part) {
+  constexpr int V = 16 / sizeof(T), RPW = 64 / SUB;
+  const int cvec = C / V, lane = threadIdx.x & 63, sub = lane % SUB, rsel = lane / SUB;
   const long wave = ((long)blockIdx.x * TPB + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * TPB) >> 6;
-  float pb[2][V], pg[2][V];
+  float pb[2][V], pg[2][V], ga[2][V], be[2][V];
 #pragma unroll
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < 2; ++k) {
+    const int cv = sub + SUB * k;
 #pragma unroll
-    for (int e = 0; e < V; ++e) pb[k][e] = pg[k][e] = 0.f;
-  for (long r = wave; r < rows; r += nwaves) {
-    const float mu = mean[r], rs = rstd[r];
+    for (int e = 0; e < V; ++e) {
+      pb[k][e] = pg[k][e] = 0.f;
+      ga[k][e] = cv < cvec ? gamma[cv * V + e] : 0.f;
+      be[k][e] = cv < cvec ? beta[cv * V + e] : 0.f;
+    }
+  }
+  for (long r0 = wave * RPW; r0 < rows; r0 += nwaves * RPW) {
+    const long r = r0 + rsel;
+    const bool rok = r < rows;
+    const float mu = rok ? mean[r] : 0.f, rs = rok ? rstd[r] : 0.f;
     float xh[2][V], gh[2][V];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int cv = lane + 64 * k;
-      if (cv < cvec) {
+      const int cv = sub + SUB * k;
+#pragma unroll
+      for (int e = 0; e < V; ++e) xh[k][e] = gh[k][e] = 0.f;
+      if (rok && cv < cvec) {
         float fz[V], fd[V];
         ldv(z + (r * cvec + cv) * V, fz);
         ldv(dy + (r * cvec + cv) * V, fd);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-          const int c = cv * V + e;
           const float x = (fz[e] - mu) * rs;
-          const float g = fd[e] * act_grad(x * gamma[c] + beta[c], act);
+          const float g = fd[e] * act_grad_c<ACT>(x * ga[k][e] + be[k][e]);
           pb[k][e] += g;
           pg[k][e] += g * x;
           xh[k][e] = x;
-          gh[k][e] = g * gamma[c];
+          gh[k][e] = g * ga[k][e];
           s1 += gh[k][e];
           s2 += gh[k][e] * x;
         }
       }
     }
-    s1 = wave_sum(s1) / C;
-    s2 = wave_sum(s2) / C;
+    s1 = sub_sum<SUB>(s1) / C;
+    s2 = sub_sum<SUB>(s2) / C;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int cv = lane + 64 * k;
-      if (cv < cvec) {
+      const int cv = sub + SUB * k;
+      if (rok && cv < cvec) {
         float o[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) o[e] = rs * (gh[k][e] - s1 - xh[k][e] * s2);
@@ -829,30 +892,62 @@ __global__ void layernorm_act_bwd_kernel(const T* __restrict__ z, const T* __res
       }
     }
   }
+  // fold the row groups of the wave together, then lanes < SUB write the wave's partial row
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int cv = lane + 64 * k;
-    if (cv < cvec) {
+  for (int k = 0; k < 2; ++k)
 #pragma unroll
-      for (int e = 0; e < V; ++e) {
-        part[(wave * 2 + 0) * C + cv * V + e] = pb[k][e];
-        part[(wave * 2 + 1) * C + cv * V + e] = pg[k][e];
+    for (int e = 0; e < V; ++e) {
+#pragma unroll
+      for (int o = 32; o >= SUB; o >>= 1) {
+        pb[k][e] += __shfl_xor(pb[k][e], o);
+        pg[k][e] += __shfl_xor(pg[k][e], o);
+      }
+    }
+  if (rsel == 0) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int cv = sub + SUB * k;
+      if (cv < cvec) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          part[(wave * 2 + 0) * C + cv * V + e] = pb[k][e];
+          part[(wave * 2 + 1) * C + cv * V + e] = pg[k][e];
+        }
       }
     }
   }
 }
 
-// column sums of a [rows][C] tensor: part [nblk*nrl][C]
-template <typename T>
+// column sums of a [rows][C] tensor: part [nblk*nrl][C]; VECTOR: 16-byte loads, thread = (channel vector, row lane)
+template <typename T, bool VECTOR>
 __global__ void colsum_partial_kernel(const T* __restrict__ x, long rows, int C, float* __restrict__ part,
                                       int rows_per_block, int nrl) {
+  constexpr int V = 16 / sizeof(T);
   const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  const int rl = threadIdx.x / C;
-  if (rl >= nrl) return;
-  for (int c = threadIdx.x % C; c < C; c += TPB) {
-    float s = 0.f;
-    for (long r = r0 + rl; r < r1; r += nrl) s += elem<T>::ld(x + r * C + c);
-    part[((long)blockIdx.x * nrl + rl) * C + c] = s;
+  if (VECTOR) {
+    const int cvec = C / V, rl = threadIdx.x / cvec;
+    if (rl >= nrl) return;
+    for (int cv = threadIdx.x % cvec; cv < cvec; cv += TPB) {
+      float acc[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] = 0.f;
+      for (long r = r0 + rl; r < r1; r += nrl) {
+        float f[V];
+        ldv(x + (r * cvec + cv) * V, f);
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] += f[e];
+      }
+#pragma unroll
+      for (int e = 0; e < V; ++e) part[((long)blockIdx.x * nrl + rl) * C + cv * V + e] = acc[e];
+    }
+  } else {
+    const int rl = threadIdx.x / C;
+    if (rl >= nrl) return;
+    for (int c = threadIdx.x % C; c < C; c += TPB) {
+      float s = 0.f;
+      for (long r = r0 + rl; r < r1; r += nrl) s += elem<T>::ld(x + r * C + c);
+      part[((long)blockIdx.x * nrl + rl) * C + c] = s;
+    }
   }
 }
 
@@ -878,8 +973,28 @@ inline int grid_for(long n) {
   if (g < 1) g = 1;
   return (int)g;
 }
+// grid for per-channel kernels: total threads a multiple of cvec when possible (threads then keep their channels)
+inline int grid_fixed(long nvec, int cvec, bool* fixed) {
+  int g = grid_for(nvec);
+  *fixed = false;
+  if (cvec <= TPB && TPB % cvec == 0) { *fixed = true; return g; }
+  // otherwise look for a block count with (g * TPB) % cvec == 0 close below g
+  for (int t = g; t >= 1 && t > g - 64; --t)
+    if (((long)t * TPB) % cvec == 0) { *fixed = true; return t; }
+  return g;
+}
 
 }  // namespace
+
+#define SIHL_AFF(A, F) hipLaunchKernelGGL((affine_act_kernel<T, A, F>), dim3(g), dim3(TPB), 0, stream, (const T*)x, (T*)y, nvec, C / V, scale, shift)
+#define SIHL_AFF_A(A) do { if (fixed) SIHL_AFF(A, true); else SIHL_AFF(A, false); } while (0)
+#define SIHL_AFB(A, F) hipLaunchKernelGGL((affine_act_bwd_kernel<T, A, F>), dim3(g), dim3(TPB), 0, stream, (const T*)x, (const T*)dy, (T*)dx, nvec, C / V, scale, shift)
+#define SIHL_AFB_A(A) do { if (fixed) SIHL_AFB(A, true); else SIHL_AFB(A, false); } while (0)
+#define SIHL_NBA(M, A, F) hipLaunchKernelGGL((norm_bwd_apply_kernel<T, M, A, F>), dim3(g), dim3(TPB), 0, stream, (const T*)s, (const T*)dy, (T*)dz, nvec, C / V, mean, rstd, gamma, beta, (const float*)sums, 1.f / (float)rows, batch_stats)
+#define SIHL_NBA_F(M, A) do { if (fixed) SIHL_NBA(M, A, true); else SIHL_NBA(M, A, false); } while (0)
+
+#define SIHL_LN(S, A) hipLaunchKernelGGL((layernorm_act_kernel<T, S, A>), dim3((int)g), dim3(TPB), 0, stream, (const T*)z, (T*)y, rows, C, gamma, beta, eps, mean, rstd)
+#define SIHL_LNB(S, A) hipLaunchKernelGGL((layernorm_act_bwd_kernel<T, S, A>), dim3(nwaves / 4), dim3(TPB), 0, stream, (const T*)z, (const T*)dy, (T*)dz, rows, C, gamma, beta, mean, rstd, ws)
 
 #define DISPATCH_DTYPE(dtype, ...)                                   \
   if (dtype == SIHL_F32) { typedef float T; __VA_ARGS__; }           \
@@ -914,8 +1029,14 @@ int sihl_affine_act(const void* x, void* y, long rows, int C, const float* scale
     constexpr int V = 16 / sizeof(T);
     if (C % V) return SIHL_EARG;
     const long nvec = rows * (C / V);
-    hipLaunchKernelGGL(affine_act_kernel<T>, dim3(grid_for(nvec)), dim3(TPB), 0, stream, (const T*)x, (T*)y, nvec,
-                       C / V, scale, shift, act);
+    bool fixed;
+    const int g = grid_fixed(nvec, C / V, &fixed);
+    switch (act) {
+      case SIHL_ACT_RELU: SIHL_AFF_A(SIHL_ACT_RELU); break;
+      case SIHL_ACT_SILU: SIHL_AFF_A(SIHL_ACT_SILU); break;
+      case SIHL_ACT_SIGMOID: SIHL_AFF_A(SIHL_ACT_SIGMOID); break;
+      default: SIHL_AFF_A(SIHL_ACT_NONE); break;
+    }
   });
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
@@ -928,8 +1049,14 @@ int sihl_affine_act_bwd(const void* x, const void* dy, void* dx, long rows, int 
     constexpr int V = 16 / sizeof(T);
     if (C % V) return SIHL_EARG;
     const long nvec = rows * (C / V);
-    hipLaunchKernelGGL(affine_act_bwd_kernel<T>, dim3(grid_for(nvec)), dim3(TPB), 0, stream, (const T*)x,
-                       (const T*)dy, (T*)dx, nvec, C / V, scale, shift, act);
+    bool fixed;
+    const int g = grid_fixed(nvec, C / V, &fixed);
+    switch (act) {
+      case SIHL_ACT_RELU: SIHL_AFB_A(SIHL_ACT_RELU); break;
+      case SIHL_ACT_SILU: SIHL_AFB_A(SIHL_ACT_SILU); break;
+      case SIHL_ACT_SIGMOID: SIHL_AFB_A(SIHL_ACT_SIGMOID); break;
+      default: SIHL_AFB_A(SIHL_ACT_NONE); break;
+    }
   });
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
@@ -1110,7 +1237,7 @@ long sihl_norm_act_bwd_ws_bytes(long rows, int C, int dtype) {
   const int cvec = C / (dtype == SIHL_BF16 ? 8 : 4);
   return ((long)reduce_blocks(rows) * row_lanes(cvec) * 2 * C + 2L * C) * (long)sizeof(float);
 }
-long sihl_colsum_ws_bytes(long rows, int C) { return (long)reduce_blocks(rows) * row_lanes(C) * C * (long)sizeof(float); }
+long sihl_colsum_ws_bytes(long rows, int C) { return (long)reduce_blocks(rows) * TPB * 8 * (long)sizeof(float) + (long)reduce_blocks(rows) * row_lanes(C) * C * (long)sizeof(float); }
 
 int sihl_norm_act_bwd(const void* s, const void* dy, void* dz, long rows, int C, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, float* dgamma, float* dbeta, int mode, int act,
@@ -1129,9 +1256,20 @@ int sihl_norm_act_bwd(const void* s, const void* dy, void* dz, long rows, int C,
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, stream, (const float*)ws,
                        nblk * nrl, 2, C, sums);
     const long nvec = rows * (C / V);
-    hipLaunchKernelGGL(norm_bwd_apply_kernel<T>, dim3(grid_for(nvec)), dim3(TPB), 0, stream, (const T*)s,
-                       (const T*)dy, (T*)dz, nvec, C / V, mean, rstd, gamma, beta, (const float*)sums,
-                       1.f / (float)rows, mode, act, batch_stats);
+    bool fixed;
+    const int g = grid_fixed(nvec, C / V, &fixed);
+    if (mode == 0) {
+      if (act == SIHL_ACT_RELU) SIHL_NBA_F(0, SIHL_ACT_RELU);
+      else if (act == SIHL_ACT_NONE) SIHL_NBA_F(0, SIHL_ACT_NONE);
+      else return SIHL_EARG;  // act->norm backward needs the pre-activation for silu/sigmoid: not a hot-path block
+    } else {
+      switch (act) {
+        case SIHL_ACT_RELU: SIHL_NBA_F(1, SIHL_ACT_RELU); break;
+        case SIHL_ACT_SILU: SIHL_NBA_F(1, SIHL_ACT_SILU); break;
+        case SIHL_ACT_SIGMOID: SIHL_NBA_F(1, SIHL_ACT_SIGMOID); break;
+        default: SIHL_NBA_F(1, SIHL_ACT_NONE); break;
+      }
+    }
   });
   if (dbeta) { hipError_t e = hipMemcpyAsync(dbeta, sums, C * sizeof(float), hipMemcpyDeviceToDevice, stream); if (e) return (int)e; }
   if (dgamma) { hipError_t e = hipMemcpyAsync(dgamma, sums + C, C * sizeof(float), hipMemcpyDeviceToDevice, stream); if (e) return (int)e; }
@@ -1147,8 +1285,10 @@ int sihl_layernorm_act(const void* z, void* y, long rows, int C, const float* ga
     if (C % V || C / V > 128) return SIHL_EARG;
     long g = (rows + 3) / 4;
     if (g > 256 * 8) g = 256 * 8;
-    hipLaunchKernelGGL(layernorm_act_kernel<T>, dim3((int)g), dim3(TPB), 0, stream, (const T*)z, (T*)y, rows, C, gamma,
-                       beta, eps, act, mean, rstd);
+    const int cvec = C / V;
+    if (act != SIHL_ACT_SILU && act != SIHL_ACT_NONE) return SIHL_EARG;
+    if (act == SIHL_ACT_SILU) { if (cvec <= 32) SIHL_LN(16, SIHL_ACT_SILU); else if (cvec <= 64) SIHL_LN(32, SIHL_ACT_SILU); else SIHL_LN(64, SIHL_ACT_SILU); }
+    else { if (cvec <= 32) SIHL_LN(16, SIHL_ACT_NONE); else if (cvec <= 64) SIHL_LN(32, SIHL_ACT_NONE); else SIHL_LN(64, SIHL_ACT_NONE); }
   });
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
@@ -1176,8 +1316,10 @@ int sihl_layernorm_act_bwd(const void* z, const void* dy, void* dz, long rows, i
   DISPATCH_DTYPE(dtype, {
     constexpr int V = 16 / sizeof(T);
     if (C % V || C / V > 128) return SIHL_EARG;
-    hipLaunchKernelGGL(layernorm_act_bwd_kernel<T>, dim3(nwaves / 4), dim3(TPB), 0, stream, (const T*)z, (const T*)dy,
-                       (T*)dz, rows, C, gamma, beta, mean, rstd, act, ws);
+    const int cvec = C / V;
+    if (act != SIHL_ACT_SILU && act != SIHL_ACT_NONE) return SIHL_EARG;
+    if (act == SIHL_ACT_SILU) { if (cvec <= 32) SIHL_LNB(16, SIHL_ACT_SILU); else if (cvec <= 64) SIHL_LNB(32, SIHL_ACT_SILU); else SIHL_LNB(64, SIHL_ACT_SILU); }
+    else { if (cvec <= 32) SIHL_LNB(16, SIHL_ACT_NONE); else if (cvec <= 64) SIHL_LNB(32, SIHL_ACT_NONE); else SIHL_LNB(64, SIHL_ACT_NONE); }
   });
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, stream, (const float*)ws, nwaves,
                      2, C, sums);
@@ -1190,11 +1332,19 @@ int sihl_layernorm_act_bwd(const void* z, const void* dy, void* dz, long rows, i
 // out[c] = sum_r x[r][c]   (bias gradients).  ws: sihl_colsum_ws_bytes(rows, C)
 int sihl_colsum(const void* x, long rows, int C, float* out, int dtype, float* ws, long ws_bytes, hipStream_t stream) {
   if (!x || !out || rows <= 0 || C <= 0 || !ws) return SIHL_EARG;
-  const int nblk = reduce_blocks(rows), nrl = row_lanes(C);
+  const int nblk = reduce_blocks(rows);
   if (ws_bytes < sihl_colsum_ws_bytes(rows, C)) return SIHL_EWS;
   const int rpb = (int)((rows + nblk - 1) / nblk);
+  int nrl = row_lanes(C);
   DISPATCH_DTYPE(dtype, {
-    hipLaunchKernelGGL(colsum_partial_kernel<T>, dim3(nblk), dim3(TPB), 0, stream, (const T*)x, rows, C, ws, rpb, nrl);
+    constexpr int V = 16 / sizeof(T);
+    if (C % V == 0) {
+      nrl = row_lanes(C / V);
+      if (nrl > row_lanes(C) * V) nrl = row_lanes(C) * V;  // workspace was sized for row_lanes(C) * C floats
+      hipLaunchKernelGGL((colsum_partial_kernel<T, true>), dim3(nblk), dim3(TPB), 0, stream, (const T*)x, rows, C, ws, rpb, nrl);
+    } else {
+      hipLaunchKernelGGL((colsum_partial_kernel<T, false>), dim3(nblk), dim3(TPB), 0, stream, (const T*)x, rows, C, ws, rpb, nrl);
+    }
   });
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, (const float*)ws,
                      nblk * nrl, 1, C, out);
