@@ -603,11 +603,17 @@ int dispatch(const ConvParams& p, hipStream_t stream) {
   }
   if (p.Cout > 128) {
     // 256-pixel x 256-channel tiles (8 waves) halve the weight-panel traffic per flop; worth it once the
-    // grid still fills the chip
+    // grid still fills the chip.  Small pyramid levels are latency-bound (a K loop of KH*KW*Cin/64 stages
+    // on a handful of workgroups): narrower channel tiles spread them over 2-4x more CUs.
+    const long tiles128 = (p.M + 127) / 128;
     if constexpr (sizeof(T) == 2) {
       if (g_tile_override == 256 || (g_tile_override == 0 && p.M >= 256 * 256))
         return launch_dma<T, 256, 256, 4, 2>(p, stream);
     }
+    if (g_tile_override == 64 || (g_tile_override == 0 && tiles128 * ((p.Cout + 255) / 256) <= 64))
+      return launch_dma<T, 128, 64, 4, 1>(p, stream);
+    if (g_tile_override == 1280 || (g_tile_override == 0 && tiles128 * ((p.Cout + 255) / 256) <= 256))
+      return launch_dma<T, 128, 128, 2, 2>(p, stream);
     return launch_dma<T, 128, 256, 2, 2>(p, stream);
   }
   if (p.Cout > 64) return launch_dma<T, 128, 128, 2, 2>(p, stream);

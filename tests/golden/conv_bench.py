@@ -26,7 +26,7 @@ def timeit(fn, n=20):
     return (time.perf_counter() - t0) / n
 
 
-modes = [("bm128", 128), ("bm256", 256)]
+modes = [("auto", 0), ("bn256", 128), ("bn128", 1280), ("bn64", 64)]
 for name, N, H, W, Cin, Cout, K in SHAPES:
     x = torch.randn(N, H, W, Cin, device=dev, dtype=dt)
     w = torch.randn(Cout, K, K, Cin, device=dev, dtype=dt) * 0.05
