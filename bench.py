@@ -74,7 +74,7 @@ def usable_cores():
     return cores
 
 
-def cpu_baseline(sample_batch, size, iters=2):
+def cpu_baseline(sample_batch, size, iters=4):
     """The oracle (CPU port of the reference path) on a bounded sample: same model, same step, fp32."""
     import types
 
@@ -107,7 +107,10 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=2)
+    ap.add_argument("--cpu-sample", type=int, default=4)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (with --backend gloo on a one-GPU box)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,11 +120,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the hot path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = 0 if args.same_device else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     import sihl_amd
     from sihl_amd import _C

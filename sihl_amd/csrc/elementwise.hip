@@ -52,12 +52,12 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int R, int C,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* running_mean, float* running_var, float* mean_out,
                                    float* rstd_out, float* scale, float* shift) {
-  __shared__ double sh[2][4][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cx;
+  __shared__ double sh[2][16][17];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cx;
   double s = 0.0, q = 0.0;
   if (c < C)
-    for (int r = ry; r < R; r += 4) {
+    for (int r = ry; r < R; r += 16) {
       s += (double)part[((long)r * 2 + 0) * C + c];
       q += (double)part[((long)r * 2 + 1) * C + c];
     }
@@ -65,8 +65,9 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int R, int C,
   sh[1][ry][cx] = q;
   __syncthreads();
   if (ry == 0 && c < C) {
-    s = sh[0][0][cx] + sh[0][1][cx] + sh[0][2][cx] + sh[0][3][cx];
-    q = sh[1][0][cx] + sh[1][1][cx] + sh[1][2][cx] + sh[1][3][cx];
+    s = q = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { s += sh[0][k][cx]; q += sh[1][k][cx]; }
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -705,26 +706,29 @@ __global__ void norm_bwd_reduce_kernel(const T* __restrict__ s, const T* __restr
   }
 }
 
-// out[k][c] = sum_r part[r][k][c]   (k < K).  256 threads = 64 columns x 4 row lanes, fp32 partials summed
-// in double, then the 4 lanes are combined through LDS.
+// out[k][c] = sum_r part[r][k][c]   (k < K).  256 threads = 16 columns x 16 row lanes: fp32 partials are summed
+// in double per lane, the 16 lanes are combined through LDS (grid = K*C/16 workgroups).
 __global__ void colsum_finalize_kernel(const float* __restrict__ part, int R, int K, int C, float* __restrict__ out) {
-  __shared__ double sh[4][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int idx = blockIdx.x * 64 + cx, KC = K * C;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  __shared__ double sh[16][17];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int idx = blockIdx.x * 16 + cx, KC = K * C;
+  double s0 = 0.0, s1 = 0.0;
   if (idx < KC) {
     int r = ry;
-    for (; r + 12 < R; r += 16) {
+    for (; r + 16 < R; r += 32) {
       s0 += (double)part[(long)r * KC + idx];
-      s1 += (double)part[(long)(r + 4) * KC + idx];
-      s2 += (double)part[(long)(r + 8) * KC + idx];
-      s3 += (double)part[(long)(r + 12) * KC + idx];
+      s1 += (double)part[(long)(r + 16) * KC + idx];
     }
-    for (; r < R; r += 4) s0 += (double)part[(long)r * KC + idx];
+    for (; r < R; r += 16) s0 += (double)part[(long)r * KC + idx];
   }
-  sh[ry][cx] = (s0 + s1) + (s2 + s3);
+  sh[ry][cx] = s0 + s1;
   __syncthreads();
-  if (ry == 0 && idx < KC) out[idx] = (float)(sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx]);
+  if (ry == 0 && idx < KC) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[k][cx];
+    out[idx] = (float)t;
+  }
 }
 
 // dz for conv->act->BN (MODE 0) or conv->BN->act (MODE 1); batch_stats: include the mean/var terms
@@ -1007,7 +1011,7 @@ int sihl_bn_finalize(const float* partials, int n_partials, int C, long count, c
                      float eps, float momentum, float* running_mean, float* running_var, float* mean, float* rstd,
                      float* scale, float* shift, hipStream_t stream) {
   if (!partials || n_partials <= 0 || C <= 0 || count <= 0 || !mean || !rstd || !scale || !shift) return SIHL_EARG;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, partials, n_partials, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, stream, partials, n_partials, C,
                      (double)count, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
@@ -1253,7 +1257,7 @@ int sihl_norm_act_bwd(const void* s, const void* dy, void* dz, long rows, int C,
     if (C % V) return SIHL_EARG;
     hipLaunchKernelGGL(norm_bwd_reduce_kernel<T>, dim3(nblk), dim3(TPB), 0, stream, (const T*)s, (const T*)dy, rows, C,
                        mean, rstd, gamma, beta, mode, act, ws, rpb, nrl);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, stream, (const float*)ws,
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, stream, (const float*)ws,
                        nblk * nrl, 2, C, sums);
     const long nvec = rows * (C / V);
     bool fixed;
@@ -1321,7 +1325,7 @@ int sihl_layernorm_act_bwd(const void* z, const void* dy, void* dz, long rows, i
     if (act == SIHL_ACT_SILU) { if (cvec <= 32) SIHL_LNB(16, SIHL_ACT_SILU); else if (cvec <= 64) SIHL_LNB(32, SIHL_ACT_SILU); else SIHL_LNB(64, SIHL_ACT_SILU); }
     else { if (cvec <= 32) SIHL_LNB(16, SIHL_ACT_NONE); else if (cvec <= 64) SIHL_LNB(32, SIHL_ACT_NONE); else SIHL_LNB(64, SIHL_ACT_NONE); }
   });
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, stream, (const float*)ws, nwaves,
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, stream, (const float*)ws, nwaves,
                      2, C, sums);
   if (dbeta) { hipError_t e = hipMemcpyAsync(dbeta, sums, C * sizeof(float), hipMemcpyDeviceToDevice, stream); if (e) return (int)e; }
   if (dgamma) { hipError_t e = hipMemcpyAsync(dgamma, sums + C, C * sizeof(float), hipMemcpyDeviceToDevice, stream); if (e) return (int)e; }
@@ -1346,7 +1350,7 @@ int sihl_colsum(const void* x, long rows, int C, float* out, int dtype, float* w
       hipLaunchKernelGGL((colsum_partial_kernel<T, false>), dim3(nblk), dim3(TPB), 0, stream, (const T*)x, rows, C, ws, rpb, nrl);
     }
   });
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, (const float*)ws,
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, stream, (const float*)ws,
                      nblk * nrl, 1, C, out);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
