@@ -36,6 +36,9 @@ def configure_optimizer(model: nn.Module, optimizer=torch.optim.AdamW, lr: float
     for (is_bb, is_nd), params in groups.items():
         param_groups.append({"params": params, "lr": lr * (backbone_lr_factor if is_bb else 1.0),
                              "weight_decay": 0.0 if is_nd else weight_decay})
+    if optimizer in (torch.optim.AdamW, torch.optim.Adam) and "fused" not in kw and "foreach" not in kw:
+        # one multi-tensor kernel per group instead of a host loop over ~400 parameters
+        kw["fused"] = all(p.is_cuda for g in param_groups for p in g["params"])
     return optimizer(param_groups, lr=lr, weight_decay=weight_decay, **kw)
 
 
