@@ -99,9 +99,7 @@ class ObjectDetection(nn.Module):
         anchors = (offsets + scales) * full
         boxes = [b.to(device) for b in boxes]
         classes = [c.to(device) for c in classes]
-        matches = [self.bbox_matching(anchors, boxes[b], self.topk, relative=True) for b in range(B)]
-        assignment = torch.stack([m[0] for m in matches])
-        rel_iou = torch.stack([m[1] for m in matches])
+        assignment, rel_iou = self.batched_matching(anchors, boxes, self.topk)
 
         flat = self._flat_feats(inputs)
         P, C = flat.shape[1], flat.shape[2]
@@ -150,6 +148,38 @@ class ObjectDetection(nn.Module):
     def on_validation_end(self) -> Dict[str, float]:
         # box mAP needs a COCO evaluator (torchmetrics + faster_coco_eval in the reference): out of scope
         return {"loss": torch.stack(self._val_losses).mean().item() if self._val_losses else float("nan")}
+
+    @staticmethod
+    def batched_matching(anchors: Tensor, boxes: List[Tensor], topk: int) -> Tuple[Tensor, Tensor]:
+        """bbox_matching(relative=True) for the whole batch at once: ground truths are zero-padded to the
+        batch maximum and padded columns are masked out, so the result per image equals the per-image routine
+        of the reference (:143-148, :252-284) while launching ~30 kernels instead of ~30 per image."""
+        B, A = len(boxes), anchors.shape[0]
+        counts = [int(b.shape[0]) for b in boxes]  # host-side shapes: no device sync
+        G = max(counts) if counts else 0
+        device = anchors.device
+        if G == 0:
+            return (torch.full((B, A), -1, device=device, dtype=torch.int64),
+                    torch.zeros((B, A), device=device, dtype=torch.float32))
+        gt = torch.zeros((B, G, 4), device=device, dtype=torch.float32)
+        # a degenerate-free placeholder box for padded slots keeps the CIoU arithmetic finite
+        gt[..., 2:] = 1.0
+        for b, bx in enumerate(boxes):
+            if counts[b]:
+                gt[b, : counts[b]] = bx.to(torch.float32)
+        col_ok = torch.arange(G, device=device)[None, :] < torch.tensor(counts, device=device)[:, None]  # (B, G)
+        ious = complete_box_iou(anchors, gt.reshape(B * G, 4)).reshape(A, B, G).permute(1, 0, 2).clamp(0)
+        ious = ious * col_ok[:, None, :]
+        top_v, top_i = torch.topk(ious, k=topk, dim=1)  # (B, k, G)
+        in_topk = torch.zeros((B, A, G), dtype=torch.bool, device=device)
+        in_topk.scatter_(1, top_i, True)
+        in_topk &= col_ok[:, None, :]
+        best_iou, best_gt = torch.max(ious * in_topk.float(), dim=2)  # (B, A)
+        valid = in_topk.any(dim=2)
+        assign = torch.where(valid, best_gt, torch.full_like(best_gt, -1))
+        denom = torch.gather(top_v[:, 0, :], 1, best_gt)
+        rel = (best_iou / denom).nan_to_num(0)
+        return assign, torch.where(valid, rel, torch.zeros_like(rel))
 
     @staticmethod
     def bbox_matching(anchors: Tensor, gt_boxes: Tensor, topk: int, relative: bool = False):
