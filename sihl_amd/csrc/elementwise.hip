@@ -660,8 +660,8 @@ __global__ void fusion_wgrad_kernel(const float* wraw, const float* g, float* dw
 // ------------------------------------------------------------------ column sums: partial stage + final stage
 // mode 0: sums of (dy) and (dy * xhat)            [act -> norm, s = post-activation tensor]
 // mode 1: g = dy*act'(xhat*gamma+beta); sums of g and g*xhat   [norm -> act, s = pre-norm tensor]
-// Thread -> (channel vector cv, row lane rl): a block's rows are dealt to nrl = TPB/cvec row lanes, each of
-// which writes its own partial row: part[(block*nrl + rl)][2][C].
+// Thread -> (channel vector cv, row lane rl): a block's rows are dealt to nrl = TPB/cvec row lanes, folded
+// through LDS into ONE partial row per block: part[block][2][C].
 template <typename T>
 __global__ void norm_bwd_reduce_kernel(const T* __restrict__ s, const T* __restrict__ dy, long rows, int C,
                                        const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -672,8 +672,8 @@ __global__ void norm_bwd_reduce_kernel(const T* __restrict__ s, const T* __restr
   const long r0 = (long)blockIdx.x * rows_per_block;
   const long r1 = min(rows, r0 + rows_per_block);
   const int rl = threadIdx.x / cvec;
-  if (rl >= nrl) return;
-  for (int cv = threadIdx.x % cvec; cv < cvec; cv += TPB) {
+  extern __shared__ float red_lds[];  // [nrl][2][C]
+  for (int cv = threadIdx.x % cvec; cv < cvec && rl < nrl; cv += TPB) {
     float sb[V], sg[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) sb[e] = sg[e] = 0.f;
@@ -697,12 +697,18 @@ __global__ void norm_bwd_reduce_kernel(const T* __restrict__ s, const T* __restr
         sg[e] += g * xh;
       }
     }
-    const long prow = (long)blockIdx.x * nrl + rl;
+    // fold the nrl row lanes of this block through LDS: one partial row per block
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-      part[(prow * 2 + 0) * C + cv * V + e] = sb[e];
-      part[(prow * 2 + 1) * C + cv * V + e] = sg[e];
+      red_lds[(rl * 2 + 0) * C + cv * V + e] = sb[e];
+      red_lds[(rl * 2 + 1) * C + cv * V + e] = sg[e];
     }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 2 * C; idx += TPB) {
+    float t = 0.f;
+    for (int l = 0; l < nrl; ++l) t += red_lds[l * 2 * C + idx];
+    part[(long)blockIdx.x * 2 * C + idx] = t;
   }
 }
 
@@ -1255,10 +1261,11 @@ int sihl_norm_act_bwd(const void* s, const void* dy, void* dz, long rows, int C,
   DISPATCH_DTYPE(dtype, {
     constexpr int V = 16 / sizeof(T);
     if (C % V) return SIHL_EARG;
-    hipLaunchKernelGGL(norm_bwd_reduce_kernel<T>, dim3(nblk), dim3(TPB), 0, stream, (const T*)s, (const T*)dy, rows, C,
-                       mean, rstd, gamma, beta, mode, act, ws, rpb, nrl);
+    if (C / V > TPB) return SIHL_EARG;  // one thread per channel vector
+    hipLaunchKernelGGL(norm_bwd_reduce_kernel<T>, dim3(nblk), dim3(TPB), (size_t)nrl * 2 * C * sizeof(float), stream,
+                       (const T*)s, (const T*)dy, rows, C, mean, rstd, gamma, beta, mode, act, ws, rpb, nrl);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, stream, (const float*)ws,
-                       nblk * nrl, 2, C, sums);
+                       nblk, 2, C, sums);
     const long nvec = rows * (C / V);
     bool fixed;
     const int g = grid_fixed(nvec, C / V, &fixed);
