@@ -34,7 +34,13 @@ def _p(t: Optional[Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """Raw handle of torch's current HIP stream (the fast path avoids building a Stream object per launch)."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -43,7 +49,7 @@ _WS = {}
 
 def workspace(nbytes: int, device) -> Tensor:
     """Grow-only scratch buffer per device (kernels are stream-ordered, so one buffer is shared)."""
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    key = (device.index, _stream().value)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -118,8 +124,7 @@ def weight_for_dgrad(w: Tensor, flip: bool) -> Tensor:
 
 def bn_finalize(stats: Tensor, count: int, gamma, beta, eps, momentum, running_mean, running_var):
     C = stats.shape[-1]
-    dev = stats.device
-    mean, rstd, scale, shift = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4))
+    mean, rstd, scale, shift = torch.empty((4, C), dtype=torch.float32, device=stats.device).unbind(0)
     rc = _C.lib().sihl_bn_finalize(_p(stats), stats.shape[0], C, count, _p(gamma), _p(beta), eps, momentum,
                                    _p(running_mean), _p(running_var), _p(mean), _p(rstd), _p(scale), _p(shift),
                                    _stream())
