@@ -68,6 +68,9 @@ int sihl_conv2d_dgrad(const void* dout, const void* wt_t, void* din, int N, int 
 
 /* Weight gradient (autograd of Conv2d.weight / Linear.weight): dw fp32 [Cout][KH][KW][Cin];
  * accumulate != 0 adds into dw.  Cin, Cout % vector == 0. */
+/* Test hook: bf16 layers with >= 128 channels use an LDS-DMA 256x256-panel kernel; on != 0 forces the
+ * register-staged 128x128 kernel (the fp32 / small-channel path) so both stay parity-tested. */
+int sihl_conv2d_wgrad_force_register_staging(int on);
 long sihl_conv2d_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                 int dil, int dtype);
 int sihl_conv2d_wgrad(const void* in, const void* dout, float* dw, int N, int H, int W, int Cin, int Cout, int KH,

@@ -24,6 +24,7 @@ SIGNATURES = {
     "sihl_conv2d_debug": (I, [I]),
     "sihl_conv2d_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, P, P, P, I, P, L, L, P]),
     "sihl_conv2d_dgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "sihl_conv2d_wgrad_force_register_staging": (I, [I]),
     "sihl_conv2d_wgrad_ws_bytes": (L, [I, I, I, I, I, I, I, I, I, I, I]),
     "sihl_conv2d_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, L, P]),
     "sihl_weight_flip_transpose": (I, [P, P, I, I, I, I, I, I, I, P]),

@@ -11,6 +11,7 @@
 // Workgroup = 128 co x 128 ci of one tap over one K-split of the pixels; fp32 partial tiles go to
 // a workspace [split][Cout][taps][Cin] and sihl_wgrad_reduce sums the splits (deterministic).
 #include "common.h"
+#include "dma.h"
 #include "profile.h"
 
 namespace {
@@ -185,6 +186,168 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// bf16 LDS-DMA variant (the default for >= 128-channel layers): one workgroup of 8 waves owns the whole
+// 256 co x 256 ci panel of ONE tap over a K-split of the pixels.  Per stage 64 pixels of dout and of the
+// tap-shifted input go global -> LDS by buffer_load ... lds (rows of 512 B, unpadded); the MFMA operands are
+// k-contiguous per lane, so they are read TRANSPOSED with ds_read_b64_tr_b16.  A 16-lane group of that
+// instruction touches 4 consecutive pixel rows x 64 B, which on 512-byte rows would all hit the same bank
+// window: the 64-byte block index of a row is XOR-ed with (row & 3) on the DMA source side and on the read.
+constexpr int WB = 256;        // channels per panel side
+constexpr int WKP = 64;        // pixels per stage
+constexpr int WROW = WB * 2;   // bytes per pixel row in LDS
+
+__global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(const WgradParams p) {
+  constexpr int TILE = WKP * WROW, STAGE = 2 * TILE;  // 32 KiB per operand, 64 KiB per stage
+  constexpr int NP = TILE / 1024 / 8;                 // DMA pieces per wave per operand per stage (= 4)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves, each 128 co x 64 ci
+  const int ntaps = p.KH * p.KW;
+  // Block -> (group, tap) with the taps of one (co panel, ci panel, K-split) group on ONE XCD and adjacent in
+  // dispatch order (blocks b and b+8 share an XCD): they stream the same pixels at about the same time, so
+  // dout is fetched from the fabric once instead of KH*KW times and the shifted inputs mostly hit L2.
+  const int ngroups = p.tiles_co * p.tiles_ci * p.splits;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int grp = (idx / ntaps) * 8 + xcd;
+  const int tap = idx % ntaps;
+  if (grp >= ngroups) return;
+  int b = grp;
+  const int split = b % p.splits; b /= p.splits;
+  const int tci = b % p.tiles_ci; b /= p.tiles_ci;
+  const int tco = b;
+  const int ky = tap / p.KW, kx = tap - ky * p.KW;
+  const int co0 = tco * WB, ci0 = tci * WB;
+  const int k_begin = split * p.m_per_split;
+  const int k_end = min(p.M, k_begin + p.m_per_split);
+  const int nstages = (k_end - k_begin + WKP - 1) / WKP;
+
+  const v4i_t dy_rsrc = make_rsrc(p.dout, (unsigned)((long)p.M * p.Cout * 2));
+  const v4i_t in_rsrc = make_rsrc(p.in, (unsigned)((long)p.N * p.H * p.W * p.Cin * 2));
+  const unsigned lds_base = (unsigned)(unsigned long)(lds_ptr_t)smem;
+  const int hw = p.Ho * p.Wo;
+
+  // slot j of this wave covers LDS rows (wave*NP + j)*2 + (lane >> 5); lane & 31 is the 16-byte position, which
+  // holds source chunk  pos ^ ((row & 3) << 2).  Each slot walks the pixels k_begin + row, +64, +128, ...: its
+  // (image, oy, ox) is advanced incrementally (no division inside the K loop).
+  int s_ch[NP], s_m[NP], s_n[NP], s_oy[NP], s_ox[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int row = (wave * NP + j) * 2 + (lane >> 5);
+    s_ch[j] = ((lane & 31) ^ ((row & 3) << 2)) * 8;  // channel offset inside the 256-wide panel
+    s_m[j] = k_begin + row;
+    const int mm = min(s_m[j], p.M - 1);
+    s_n[j] = mm / hw;
+    const int r = mm - s_n[j] * hw;
+    s_oy[j] = r / p.Wo;
+    s_ox[j] = r - s_oy[j] * p.Wo;
+  }
+  const int step_ox = WKP % p.Wo, step_rows = WKP / p.Wo;
+  const int step_oy = step_rows % p.Ho, step_n = step_rows / p.Ho;
+  auto issue_slot = [&](int j, unsigned abase, unsigned bbase) {
+    const int m = s_m[j];
+    const bool mok = m < k_end;
+    const int co = co0 + s_ch[j], ci = ci0 + s_ch[j];
+    dma16((mok && co < p.Cout) ? (unsigned)(m * p.Cout + co) * 2u : OOB, abase + j * 1024, dy_rsrc);
+    const int iy = s_oy[j] * p.stride - p.pad + ky * p.dil, ix = s_ox[j] * p.stride - p.pad + kx * p.dil;
+    const bool ok = mok && ci < p.Cin && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+    dma16(ok ? (unsigned)(((s_n[j] * p.H + iy) * p.W + ix) * p.Cin + ci) * 2u : OOB, bbase + j * 1024, in_rsrc);
+    // advance this slot by one stage (64 pixels)
+    s_m[j] += WKP;
+    s_ox[j] += step_ox;
+    s_oy[j] += step_oy;
+    s_n[j] += step_n;
+    if (s_ox[j] >= p.Wo) { s_ox[j] -= p.Wo; s_oy[j] += 1; }
+    if (s_oy[j] >= p.Ho) { s_oy[j] -= p.Ho; s_n[j] += 1; }
+  };
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transposed-read geometry: group g = lane>>4 reads 4 pixel rows x 16 channels; lane 4q+pp gives row q,
+  // channels 4pp..4pp+3 and receives channel (lane & 15) of the 4 rows.  (row & 3) == q for both reads.
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, h = g >> 1;
+  const int rowsel = 8 * h + q;                        // + 16*ks (+4 for the second read)
+  const int colb = (16 * (g & 1) + 4 * pp) * 2;        // byte column inside a 32-channel MFMA tile
+  auto tr_addr = [&](int row, int chan_base_bytes) {   // swizzled byte offset of (row, channel byte) in a tile
+    const int cb = chan_base_bytes + colb;
+    return row * WROW + ((((cb >> 6) ^ (row & 3)) << 6) | (cb & 63));
+  };
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  auto compute = [&](int buf, bool more, unsigned abase) {
+    const char* As = smem + buf * STAGE;
+    const char* Bs = As + TILE;
+#pragma unroll
+    for (int ks = 0; ks < WKP / 16; ++ks) {
+      const int row = ks * 16 + rowsel;
+      bf16x8_t a[4], bq[2];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int off = tr_addr(row, (wm * 128 + t * 32) * 2);
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(As + off));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(As + off + 4 * WROW));
+        a[t] = __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int off = tr_addr(row, (wn * 64 + t * 32) * 2);
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Bs + off));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Bs + off + 4 * WROW));
+        bq[t] = __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bq[j], acc[i][j], 0, 0, 0);
+      // the next stage's DMA goes out behind the first two k-steps' MFMAs (front-loaded, as in conv_igemm)
+      if (more && ks < 2) {
+#pragma unroll
+        for (int j = ks; j < NP; j += 2) issue_slot(j, abase, abase + TILE);
+      }
+    }
+  };
+
+  if (nstages > 0) {
+    {
+      const unsigned abase = lds_base + wave * NP * 1024;
+#pragma unroll
+      for (int j = 0; j < NP; ++j) issue_slot(j, abase, abase + TILE);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int s = 0; s < nstages; ++s) {
+      const bool more = s + 1 < nstages;
+      const unsigned abase = lds_base + ((s + 1) & 1) * STAGE + wave * NP * 1024;
+      compute(s & 1, more, abase);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+
+  const int half = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ci = ci0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co < p.Cout && ci < p.Cin)
+          p.ws[(((long)split * p.Cout + co) * ntaps + tap) * p.Cin + ci] = acc[i][j][r];
+      }
+    }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n, int splits,
                                     int accumulate) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -192,6 +355,32 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
   float s = 0.f;
   for (int k = 0; k < splits; ++k) s += ws[(long)k * n + i];
   dw[i] = accumulate ? dw[i] + s : s;
+}
+
+bool g_wgrad_force_reg = false;
+
+bool use_dma(int Cin, int Cout, long in_bytes, long dy_bytes, int dtype) {
+  return !g_wgrad_force_reg && dtype == SIHL_BF16 && Cin >= 128 && Cout >= 128 && in_bytes < (1L << 31) &&
+         dy_bytes < (1L << 31);
+}
+
+int launch_dma(WgradParams p, hipStream_t stream) {
+  constexpr int LDS = 2 * 2 * WKP * WROW;  // 128 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int ngroups = p.tiles_co * p.tiles_ci * p.splits;
+  const int grid = ((ngroups + 7) / 8) * 8 * p.KH * p.KW;
+  const double flops = 2.0 * p.M * (double)p.Cout * p.KH * p.KW * p.Cin;
+  const double bytes = ((double)p.N * p.H * p.W * p.Cin + (double)p.M * p.Cout) * 2 + (double)p.Cout * p.KH * p.KW * p.Cin * 4.0;
+  sihl_prof_begin(SIHL_PROF_WGRAD, SIHL_BF16, flops, bytes, stream);
+  hipLaunchKernelGGL(conv_wgrad_dma_kernel, dim3(grid), dim3(512), LDS, stream, p);
+  sihl_prof_end(stream);
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
 }
 
 template <typename T>
@@ -214,9 +403,9 @@ int launch(WgradParams p, hipStream_t stream) {
   return SIHL_OK;
 }
 
-int choose_splits(long M, int tiles, int kp) {
-  // aim for >= 512 workgroups, each with at least 4 stages of work
-  long want = (512 + tiles - 1) / tiles;
+int choose_splits(long M, int tiles, int kp, int target) {
+  // aim for >= `target` workgroups, each with at least 4 stages of work
+  long want = (target + tiles - 1) / tiles;
   long max_by_work = M / (4L * kp);
   if (max_by_work < 1) max_by_work = 1;
   long s = want < max_by_work ? want : max_by_work;
@@ -229,14 +418,20 @@ int choose_splits(long M, int tiles, int kp) {
 
 extern "C" {
 
+// Test hook: 1 = always use the register-staged 128x128 kernel (the fp32 / small-channel path).
+int sihl_conv2d_wgrad_force_register_staging(int on) { g_wgrad_force_reg = on != 0; return 0; }
+
 // Workspace bytes sihl_conv2d_wgrad needs for this problem.
 long sihl_conv2d_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                 int dil, int dtype) {
   const int Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
   const int Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   const long M = (long)N * Ho * Wo;
-  const int tiles = KH * KW * ((Cout + BCO - 1) / BCO) * ((Cin + BCI - 1) / BCI);
-  const int splits = choose_splits(M, tiles, dtype == SIHL_BF16 ? 64 : 32);
+  const int vs = dtype == SIHL_BF16 ? 2 : 4;
+  const bool dma = use_dma(Cin, Cout, (long)N * H * W * Cin * vs, M * Cout * vs, dtype);
+  const int tb = dma ? WB : BCO;
+  const int tiles = KH * KW * ((Cout + tb - 1) / tb) * ((Cin + tb - 1) / tb);
+  const int splits = choose_splits(M, tiles, dtype == SIHL_BF16 ? 64 : 32, dma ? 256 : 512);
   return (long)splits * Cout * KH * KW * Cin * (long)sizeof(float);
 }
 
@@ -256,15 +451,19 @@ int sihl_conv2d_wgrad(const void* in, const void* dout, float* dw, int N, int H,
   const long M = (long)N * p.Ho * p.Wo;
   if (p.Ho <= 0 || p.Wo <= 0 || M > (1L << 30)) return SIHL_EARG;
   p.M = (int)M;
-  p.tiles_co = (Cout + BCO - 1) / BCO;
-  p.tiles_ci = (Cin + BCI - 1) / BCI;
+  const int vs = dtype == SIHL_BF16 ? 2 : 4;
+  const bool dma = use_dma(Cin, Cout, (long)N * H * W * Cin * vs, M * Cout * vs, dtype);
+  const int tb = dma ? WB : BCO;
+  p.tiles_co = (Cout + tb - 1) / tb;
+  p.tiles_ci = (Cin + tb - 1) / tb;
   const int kp = dtype == SIHL_BF16 ? 64 : 32;
-  p.splits = choose_splits(M, KH * KW * p.tiles_co * p.tiles_ci, kp);
+  p.splits = choose_splits(M, KH * KW * p.tiles_co * p.tiles_ci, kp, dma ? 256 : 512);
   p.m_per_split = (int)(((M + p.splits - 1) / p.splits + kp - 1) / kp * kp);
   const long n = (long)Cout * KH * KW * Cin;
   if (ws_bytes < (long)p.splits * n * (long)sizeof(float)) return SIHL_EWS;
   int rc;
-  if (dtype == SIHL_F32) rc = launch<float>(p, stream);
+  if (dma) rc = launch_dma(p, stream);
+  else if (dtype == SIHL_F32) rc = launch<float>(p, stream);
   else if (dtype == SIHL_BF16) rc = launch<bf16_t>(p, stream);
   else return SIHL_EARG;
   if (rc) return rc;

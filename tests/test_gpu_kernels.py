@@ -33,6 +33,8 @@ CONV_SHAPES = [
     (2, 16, 16, 64, 32, 1, 2, 0),    # 1x1 stride 2 (ResNet downsample)
     (1, 1, 300, 256, 8, 1, 1, 0),    # linear head as 1x1 over rows
     (4, 64, 64, 256, 256, 3, 1, 1),  # a real L3-like tile count
+    (2, 16, 16, 512, 256, 1, 1, 0),  # lateral: two ci panels in the DMA wgrad
+    (3, 9, 11, 136, 264, 3, 1, 1),   # ragged channel panels, odd sizes
 ]
 
 
@@ -41,8 +43,10 @@ def loader(request):
     from sihl_amd import _C
     _C.lib().sihl_conv2d_force_register_staging(int(request.param == "register_staged"))
     _C.lib().sihl_conv2d_tile_override(256 if request.param == "lds_dma_bm256" else 0)
+    _C.lib().sihl_conv2d_wgrad_force_register_staging(int(request.param == "register_staged"))
     yield request.param
     _C.lib().sihl_conv2d_force_register_staging(0)
+    _C.lib().sihl_conv2d_wgrad_force_register_staging(0)
     _C.lib().sihl_conv2d_tile_override(0)
 
 
