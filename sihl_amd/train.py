@@ -46,9 +46,10 @@ class GradientAverager:
     """Bucketed, overlapped gradient all-reduce (mean) across the data-parallel group.
 
     Parameters are packed into ~bucket_mb fp32 buckets in REVERSE registration order (roughly the order
-    autograd produces their gradients).  A post-accumulate hook copies each finished gradient into its
-    bucket slice; when a bucket is full its all-reduce is issued asynchronously (RCCL runs it on its own
-    stream over xGMI while backward continues).  ``finish()`` waits and copies the averages back."""
+    autograd produces their gradients).  A post-accumulate hook counts finished gradients; when a bucket is
+    complete its gradients are packed with ONE multi-tensor copy and its all-reduce is issued asynchronously
+    (RCCL runs it on its own stream over xGMI while backward continues).  ``finish()`` waits and scatters the
+    averages back, again one multi-tensor copy per bucket."""
 
     def __init__(self, params: Sequence[Tensor], group=None, bucket_mb: float = 32.0):
         self.group = group
@@ -76,42 +77,45 @@ class GradientAverager:
     def _close(self, ps: List[Tensor]) -> None:
         n = sum(p.numel() for p in ps)
         flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
-        b = {"flat": flat, "params": ps, "pending": len(ps), "work": None}
-        off = 0
+        views, off = [], 0
         for p in ps:
-            self.where[id(p)] = (b, off)
+            # same shape AND strides as the parameter (conv weights are channels_last), so the multi-tensor copy
+            # below is a straight memcpy per parameter
+            views.append(flat[off: off + p.numel()].as_strided(p.shape, p.stride()) if p.is_contiguous(
+                memory_format=torch.channels_last) and p.dim() == 4 else flat[off: off + p.numel()].view(p.shape))
             off += p.numel()
+        b = {"flat": flat, "params": ps, "views": views, "pending": len(ps), "work": None}
+        for p in ps:
+            self.where[id(p)] = b
         self.buckets.append(b)
 
+    def _launch(self, b) -> None:
+        grads = [p.grad for p in b["params"]]
+        if any(g is None for g in grads):  # a parameter without gradient this step contributes zeros
+            b["flat"].zero_()
+        pairs = [(v, g) for v, g in zip(b["views"], grads) if g is not None]
+        torch._foreach_copy_([v for v, _ in pairs], [g for _, g in pairs])  # ONE multi-tensor kernel per bucket
+        op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
+        b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
+
     def _on_grad(self, p: Tensor) -> None:
-        b, off = self.where[id(p)]
-        b["flat"][off: off + p.numel()].view(p.shape).copy_(p.grad)
+        b = self.where[id(p)]
         b["pending"] -= 1
-        if b["pending"] == 0:
-            op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
-            b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
+        if b["pending"] == 0:  # every gradient of the bucket is final: pack it and start its all-reduce
+            self._launch(b)
 
     def finish(self) -> None:
         if self.world == 1:
             return
         for b in self.buckets:
             if b["work"] is None:  # some parameter of this bucket got no gradient this step
-                for p in b["params"]:
-                    _, off = self.where[id(p)]
-                    if p.grad is None:
-                        b["flat"][off: off + p.numel()].zero_()
-                op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
-                b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
+                self._launch(b)
         for b in self.buckets:
             b["work"].wait()
             if not self.use_avg:
                 b["flat"].div_(self.world)
-            off = 0
-            for p in b["params"]:
-                n = p.numel()
-                if p.grad is not None:
-                    p.grad.copy_(b["flat"][off: off + n].view(p.shape))
-                off += n
+            pairs = [(p.grad, v) for p, v in zip(b["params"], b["views"]) if p.grad is not None]
+            torch._foreach_copy_([g for g, _ in pairs], [v for _, v in pairs])
             b["pending"], b["work"] = len(b["params"]), None
 
 
