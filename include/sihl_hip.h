@@ -140,6 +140,10 @@ int sihl_resize_bilinear(const void* a, const void* add, void* out, int N, int H
 int sihl_resize_bilinear_bwd(const void* dout, void* da, int N, int H, int W, int Ho, int Wo, int C, int dtype,
                              hipStream_t stream);
 
+/* ---- ResNet residual merge (torchvision resnet Bottleneck / BasicBlock: out = relu(bn(conv(..)) + identity)) ------
+ * out = act(a + b), act none or relu; backward = sihl_affine_act_bwd(out, dout, relu) for both inputs. */
+int sihl_add_act(const void* a, const void* b, void* out, long numel, int act, int dtype, hipStream_t stream);
+
 /* ---- MLP hidden layers: y = act(LayerNorm(z)*gamma + beta) over [rows][C] (object_detection.py:51-61) ----- */
 int sihl_layernorm_act(const void* z, void* y, long rows, int C, const float* gamma, const float* beta, float eps,
                        int act, float* mean, float* rstd, int dtype, hipStream_t stream);

@@ -40,6 +40,7 @@ SIGNATURES = {
     "sihl_nearest_up2_add_bwd": (I, [P, P, I, I, I, I, I, P]),
     "sihl_resize_bilinear": (I, [P, P, P, I, I, I, I, I, I, I, P]),
     "sihl_resize_bilinear_bwd": (I, [P, P, I, I, I, I, I, I, I, P]),
+    "sihl_add_act": (I, [P, P, P, L, I, I, P]),
     "sihl_fuse_sum": (I, [P, P, P, P, P, L, I, I, P]),
     "sihl_fuse_sum_bwd": (I, [P, P, P, P, P, P, P, P, P, P, L, I, I, P]),
     "sihl_blur_fuse": (I, [P, P, P, P, P, I, I, I, I, I, P]),

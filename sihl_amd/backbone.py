@@ -1,10 +1,14 @@
-"""Level-list ResNet backbone on PyTorch-ROCm (reference src/sihl/torchvision_backbone.py:42-49,102-210).
+"""Level-list ResNet backbone (reference src/sihl/torchvision_backbone.py:42-49,102-210).
 
-The backbone is not a hand-kernel target of this round: it is a plain ``torch.nn``
-ResNet (torchvision's published architecture; torchvision itself is absent here) running
-channels_last on PyTorch-ROCm, honouring the reference's level contract: level 0 is the input,
-level 1 = ``relu`` BEFORE max-pool, levels 2..5 = ``layer1..layer4``, levels above 5 come from
-AntialiasedDownscaler blocks (HIP path).  Parameter names follow torchvision's under ``model.``.
+torchvision's published ResNet architecture (torchvision itself is absent here), honouring the reference's
+level contract: level 0 is the input, level 1 = ``relu`` BEFORE max-pool, levels 2..5 = ``layer1..layer4``,
+levels above 5 come from AntialiasedDownscaler blocks.  Parameter names follow torchvision's under ``model.``.
+
+Execution: the residual stages (layer1..layer4 - every 1x1 / 3x3 / strided conv + BatchNorm + ReLU + residual
+merge, forward and backward) run on the sihl HIP kernels when the input lives on a HIP device (``native``
+blocks: conv -> BN -> ReLU is the same fused conv block the FPN uses).  The 7x7 stem
+(3 input channels) + max-pool stay on PyTorch-ROCm.  On CPU tensors (BASELINE config 1, "stock PyTorch
+plumbing") the same parameters run through plain torch ops.
 """
 from typing import List
 
@@ -12,7 +16,17 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
 
+from sihl_amd import ops
 from sihl_amd.layers.scalers import AntialiasedDownscaler
+
+
+def _conv_bn(x: Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, act, training: bool) -> Tensor:
+    """conv -> BatchNorm -> act on NHWC tensors through the fused HIP conv block (torchvision order)."""
+    if training:
+        bn.num_batches_tracked += 1
+    return ops.conv_block(x, conv.weight, None, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                          stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0], act=act,
+                          order="norm_act", training=training, eps=bn.eps, momentum=bn.momentum)
 
 
 class _Basic(nn.Module):
@@ -33,6 +47,13 @@ class _Basic(nn.Module):
         idt = x if self.downsample is None else self.downsample(x)
         y = self.relu(self.bn1(self.conv1(x)))
         return self.relu(self.bn2(self.conv2(y)) + idt)
+
+    def forward_nhwc(self, x):
+        t = self.training
+        idt = x if self.downsample is None else _conv_bn(x, self.downsample[0], self.downsample[1], None, t)
+        y = _conv_bn(x, self.conv1, self.bn1, "relu", t)
+        y = _conv_bn(y, self.conv2, self.bn2, None, t)
+        return ops.add_relu(y, idt)
 
 
 class _Bottleneck(nn.Module):
@@ -57,6 +78,14 @@ class _Bottleneck(nn.Module):
         y = self.relu(self.bn1(self.conv1(x)))
         y = self.relu(self.bn2(self.conv2(y)))
         return self.relu(self.bn3(self.conv3(y)) + idt)
+
+    def forward_nhwc(self, x):
+        t = self.training
+        idt = x if self.downsample is None else _conv_bn(x, self.downsample[0], self.downsample[1], None, t)
+        y = _conv_bn(x, self.conv1, self.bn1, "relu", t)
+        y = _conv_bn(y, self.conv2, self.bn2, "relu", t)
+        y = _conv_bn(y, self.conv3, self.bn3, None, t)
+        return ops.add_relu(y, idt)
 
 
 RESNETS = {"resnet18": (_Basic, [2, 2, 2, 2]), "resnet34": (_Basic, [3, 4, 6, 3]),
@@ -83,21 +112,31 @@ class _Trunk(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
-    def forward(self, x: Tensor, n_taps: int) -> List[Tensor]:
+    def forward(self, x: Tensor, n_taps: int, native: bool = False) -> List[Tensor]:
         taps = [self.relu(self.bn1(self.conv1(x)))]
         y = self.maxpool(taps[0])
+        if native:
+            y = ops.nhwc(y)  # a view: the stem runs channels_last
         for i in range(1, 5):
             if len(taps) >= n_taps:
                 break
-            y = getattr(self, f"layer{i}")(y)
-            taps.append(y)
+            if native:
+                for block in getattr(self, f"layer{i}"):
+                    y = block.forward_nhwc(y)
+                taps.append(ops.nchw_view(y))
+            else:
+                y = getattr(self, f"layer{i}")(y)
+                taps.append(y)
         return taps[:n_taps]
 
 
 class ResNetBackbone(nn.Module):
     def __init__(self, name: str = "resnet50", pretrained: bool = False, input_channels: int = 3,
-                 top_level: int = 5, frozen_levels: int = 0):
+                 top_level: int = 5, frozen_levels: int = 0, native=None):
+        """native: None = HIP residual stages whenever the input is on a HIP device (default), False = always the
+        PyTorch ops (MIOpen on ROCm), True = require the HIP path."""
         super().__init__()
+        self.native = native
         if name not in RESNETS:
             raise ValueError(f"Architecture {name} is not supported. Select from {tuple(RESNETS)}")
         if pretrained:
@@ -131,7 +170,12 @@ class ResNetBackbone(nn.Module):
         assert input.shape[3] % 2 ** self.top_level == 0
         H, W = input.shape[2:]
         outs = [input]
-        for lvl, t in enumerate(self.model(input, self.n_taps), start=1):
+        native = input.is_cuda if self.native is None else bool(self.native)
+        if native and not input.is_cuda:
+            raise RuntimeError("native=True needs a HIP device (no CPU fallback for the HIP residual stages)")
+        if native and input.dim() == 4 and not input.is_contiguous(memory_format=torch.channels_last):
+            input = input.contiguous(memory_format=torch.channels_last)
+        for lvl, t in enumerate(self.model(input, self.n_taps, native), start=1):
             size = (H // 2 ** lvl, W // 2 ** lvl)
             outs.append(t if tuple(t.shape[2:]) == size else F.interpolate(t, size=size))
         for ds in self.downscalers:

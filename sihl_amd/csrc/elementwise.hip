@@ -164,6 +164,21 @@ __global__ void affine_act_bwd_kernel(const T* __restrict__ x, const T* __restri
   }
 }
 
+
+// ------------------------------------------------------------------ out = act(a + b)  (ResNet residual merge)
+template <typename T, int ACT>
+__global__ void add_act_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, long nvec) {
+  constexpr int V = 16 / sizeof(T);
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
+    float fa[V], fb[V];
+    ldv(a + i * V, fa);
+    ldv(b + i * V, fb);
+#pragma unroll
+    for (int e = 0; e < V; ++e) fa[e] = act_c<ACT>(fa[e] + fb[e]);
+    stv(out + i * V, fa);
+  }
+}
+
 // ------------------------------------------------------------------ bilinear x2 (align_corners=False) helpers
 struct Lerp { int i0, i1; float l0, l1; };
 __device__ __forceinline__ Lerp up2_src(int dst, int in_size) {
@@ -1162,6 +1177,22 @@ int sihl_resize_bilinear_bwd(const void* dout, void* da, int N, int H, int W, in
   return SIHL_OK;
 }
 
+// out = act(a + b) over `numel` elements (act: none or relu) - the residual merge of a ResNet block.
+// Its backward is sihl_affine_act_bwd(out, dout, ..., relu): both inputs receive dout * (out > 0).
+int sihl_add_act(const void* a, const void* b, void* out, long numel, int act, int dtype, hipStream_t stream) {
+  if (!a || !b || !out || numel <= 0 || (act != SIHL_ACT_NONE && act != SIHL_ACT_RELU)) return SIHL_EARG;
+  DISPATCH_DTYPE(dtype, {
+    constexpr int V = 16 / sizeof(T);
+    if (numel % V) return SIHL_EARG;
+    if (act == SIHL_ACT_RELU)
+      hipLaunchKernelGGL((add_act_kernel<T, SIHL_ACT_RELU>), dim3(grid_for(numel / V)), dim3(TPB), 0, stream, (const T*)a, (const T*)b, (T*)out, numel / V);
+    else
+      hipLaunchKernelGGL((add_act_kernel<T, SIHL_ACT_NONE>), dim3(grid_for(numel / V)), dim3(TPB), 0, stream, (const T*)a, (const T*)b, (T*)out, numel / V);
+  });
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
 // out = sum_i softmax(wraw)_i * x_i over n (2 or 3) same-shaped tensors of `numel` elements
 int sihl_fuse_sum(const void* x0, const void* x1, const void* x2, const float* wraw, void* out, long numel, int n,
                   int dtype, hipStream_t stream) {
@@ -1261,7 +1292,6 @@ int sihl_norm_act_bwd(const void* s, const void* dy, void* dz, long rows, int C,
   DISPATCH_DTYPE(dtype, {
     constexpr int V = 16 / sizeof(T);
     if (C % V) return SIHL_EARG;
-    if (C / V > TPB) return SIHL_EARG;  // one thread per channel vector
     hipLaunchKernelGGL(norm_bwd_reduce_kernel<T>, dim3(nblk), dim3(TPB), (size_t)nrl * 2 * C * sizeof(float), stream,
                        (const T*)s, (const T*)dy, rows, C, mean, rstd, gamma, beta, mode, act, ws, rpb, nrl);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, stream, (const float*)ws,

@@ -703,3 +703,28 @@ class CEResizeFn(torch.autograd.Function):
 
 def ce_resize(logits, targets, ignore_index):
     return CEResizeFn.apply(logits, targets, ignore_index)
+
+
+# ----------------------------------------------------------------------------- ResNet residual merge
+class AddReluFn(torch.autograd.Function):
+    """out = relu(a + b); both inputs receive dout * (out > 0)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.detach().contiguous(), b.detach().contiguous()
+        _require_gpu(a)
+        out = torch.empty_like(a)
+        rc = _C.lib().sihl_add_act(_p(a), _p(b), _p(out), a.numel(), ACT["relu"], _dt(a), _stream())
+        check(rc, "sihl_add_act")
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        g = affine_act_bwd(out, dout.contiguous(), None, None, "relu")
+        return g, g
+
+
+def add_relu(a, b):
+    return AddReluFn.apply(a, b)

@@ -35,6 +35,13 @@ CONV_SHAPES = [
     (4, 64, 64, 256, 256, 3, 1, 1),  # a real L3-like tile count
     (2, 16, 16, 512, 256, 1, 1, 0),  # lateral: two ci panels in the DMA wgrad
     (3, 9, 11, 136, 264, 3, 1, 1),   # ragged channel panels, odd sizes
+    (2, 4, 4, 512, 512, 3, 1, 1),    # ResNet layer4 shapes
+    (2, 4, 4, 2048, 512, 1, 1, 0),
+    (2, 4, 4, 512, 2048, 1, 1, 0),
+    (2, 8, 8, 512, 512, 3, 2, 1),
+    (2, 8, 8, 1024, 2048, 1, 2, 0),
+    (2, 32, 32, 64, 256, 1, 1, 0),   # ResNet layer1 shapes
+    (2, 32, 32, 64, 64, 3, 1, 1),
 ]
 
 
