@@ -403,14 +403,19 @@ int launch(WgradParams p, hipStream_t stream) {
   return SIHL_OK;
 }
 
-int choose_splits(long M, int tiles, int kp, int target) {
-  // aim for >= `target` workgroups, each with at least 4 stages of work
+int choose_splits(long M, int tiles, int kp, int target, long n_weights) {
+  // aim for >= `target` workgroups, each with at least 4 stages of work; small weight tensors (few tiles) may
+  // take many more K-splits - their fp32 partial slabs stay small - so that a streaming reduction over a huge
+  // activation (ResNet layer1: M = 524288 rows for a 64x64 weight) still spreads over the whole chip
   long want = (target + tiles - 1) / tiles;
   long max_by_work = M / (4L * kp);
   if (max_by_work < 1) max_by_work = 1;
   long s = want < max_by_work ? want : max_by_work;
+  long cap = (64L << 20) / (n_weights * 4);
+  if (cap < 64) cap = 64;
+  if (cap > 1024) cap = 1024;
   if (s < 1) s = 1;
-  if (s > 64) s = 64;
+  if (s > cap) s = cap;
   return (int)s;
 }
 
@@ -431,7 +436,7 @@ long sihl_conv2d_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, 
   const bool dma = use_dma(Cin, Cout, (long)N * H * W * Cin * vs, M * Cout * vs, dtype);
   const int tb = dma ? WB : BCO;
   const int tiles = KH * KW * ((Cout + tb - 1) / tb) * ((Cin + tb - 1) / tb);
-  const int splits = choose_splits(M, tiles, dtype == SIHL_BF16 ? 64 : 32, dma ? 256 : 512);
+  const int splits = choose_splits(M, tiles, dtype == SIHL_BF16 ? 64 : 32, dma ? 256 : 512, (long)Cout * KH * KW * Cin);
   return (long)splits * Cout * KH * KW * Cin * (long)sizeof(float);
 }
 
@@ -457,7 +462,7 @@ int sihl_conv2d_wgrad(const void* in, const void* dout, float* dw, int N, int H,
   p.tiles_co = (Cout + tb - 1) / tb;
   p.tiles_ci = (Cin + tb - 1) / tb;
   const int kp = dtype == SIHL_BF16 ? 64 : 32;
-  p.splits = choose_splits(M, KH * KW * p.tiles_co * p.tiles_ci, kp, dma ? 256 : 512);
+  p.splits = choose_splits(M, KH * KW * p.tiles_co * p.tiles_ci, kp, dma ? 256 : 512, (long)Cout * KH * KW * Cin);
   p.m_per_split = (int)(((M + p.splits - 1) / p.splits + kp - 1) / kp * kp);
   const long n = (long)Cout * KH * KW * Cin;
   if (ws_bytes < (long)p.splits * n * (long)sizeof(float)) return SIHL_EWS;

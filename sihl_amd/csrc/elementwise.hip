@@ -52,12 +52,13 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int R, int C,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* running_mean, float* running_var, float* mean_out,
                                    float* rstd_out, float* scale, float* shift) {
-  __shared__ double sh[2][16][17];
-  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cx;
+  // 256 threads = 4 channels x 64 row lanes (layers with few channels still spread over C/4 workgroups)
+  __shared__ double sh[2][64][5];
+  const int cx = threadIdx.x & 3, ry = threadIdx.x >> 2;
+  const int c = blockIdx.x * 4 + cx;
   double s = 0.0, q = 0.0;
   if (c < C)
-    for (int r = ry; r < R; r += 16) {
+    for (int r = ry; r < R; r += 64) {
       s += (double)part[((long)r * 2 + 0) * C + c];
       q += (double)part[((long)r * 2 + 1) * C + c];
     }
@@ -66,8 +67,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int R, int C,
   __syncthreads();
   if (ry == 0 && c < C) {
     s = q = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { s += sh[0][k][cx]; q += sh[1][k][cx]; }
+    for (int k = 0; k < 64; ++k) { s += sh[0][k][cx]; q += sh[1][k][cx]; }
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -677,11 +677,11 @@ __global__ void fusion_wgrad_kernel(const float* wraw, const float* g, float* dw
 // mode 1: g = dy*act'(xhat*gamma+beta); sums of g and g*xhat   [norm -> act, s = pre-norm tensor]
 // Thread -> (channel vector cv, row lane rl): a block's rows are dealt to nrl = TPB/cvec row lanes, folded
 // through LDS into ONE partial row per block: part[block][2][C].
-template <typename T>
+template <typename T, int MODE, int ACT>
 __global__ void norm_bwd_reduce_kernel(const T* __restrict__ s, const T* __restrict__ dy, long rows, int C,
                                        const float* __restrict__ mean, const float* __restrict__ rstd,
-                                       const float* __restrict__ gamma, const float* __restrict__ beta, int mode,
-                                       int act, float* __restrict__ part, int rows_per_block, int nrl) {
+                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       float* __restrict__ part, int rows_per_block, int nrl) {
   constexpr int V = 16 / sizeof(T);
   const int cvec = C / V;
   const long r0 = (long)blockIdx.x * rows_per_block;
@@ -707,7 +707,7 @@ __global__ void norm_bwd_reduce_kernel(const T* __restrict__ s, const T* __restr
       for (int e = 0; e < V; ++e) {
         const float xh = (fs[e] - mu[e]) * rs[e];
         float g = fd[e];
-        if (mode == 1) g *= act_grad(xh * ga[e] + be[e], act);
+        if (MODE == 1) g *= act_grad_c<ACT>(xh * ga[e] + be[e]);
         sb[e] += g;
         sg[e] += g * xh;
       }
@@ -727,27 +727,27 @@ __global__ void norm_bwd_reduce_kernel(const T* __restrict__ s, const T* __restr
   }
 }
 
-// out[k][c] = sum_r part[r][k][c]   (k < K).  256 threads = 16 columns x 16 row lanes: fp32 partials are summed
-// in double per lane, the 16 lanes are combined through LDS (grid = K*C/16 workgroups).
+// out[k][c] = sum_r part[r][k][c]   (k < K).  256 threads = 4 columns x 64 row lanes: fp32 partials are summed in
+// double per lane, the 64 lanes are combined through LDS (grid = K*C/4 workgroups, so even 64-channel layers
+// spread over 32+ CUs).
 __global__ void colsum_finalize_kernel(const float* __restrict__ part, int R, int K, int C, float* __restrict__ out) {
-  __shared__ double sh[16][17];
-  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
-  const int idx = blockIdx.x * 16 + cx, KC = K * C;
+  __shared__ double sh[64][5];
+  const int cx = threadIdx.x & 3, ry = threadIdx.x >> 2;
+  const int idx = blockIdx.x * 4 + cx, KC = K * C;
   double s0 = 0.0, s1 = 0.0;
   if (idx < KC) {
     int r = ry;
-    for (; r + 16 < R; r += 32) {
+    for (; r + 64 < R; r += 128) {
       s0 += (double)part[(long)r * KC + idx];
-      s1 += (double)part[(long)(r + 16) * KC + idx];
+      s1 += (double)part[(long)(r + 64) * KC + idx];
     }
-    for (; r < R; r += 16) s0 += (double)part[(long)r * KC + idx];
+    for (; r < R; r += 64) s0 += (double)part[(long)r * KC + idx];
   }
   sh[ry][cx] = s0 + s1;
   __syncthreads();
   if (ry == 0 && idx < KC) {
     double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += sh[k][cx];
+    for (int k = 0; k < 64; ++k) t += sh[k][cx];
     out[idx] = (float)t;
   }
 }
@@ -1015,6 +1015,7 @@ inline int grid_fixed(long nvec, int cvec, bool* fixed) {
 #define SIHL_AFF_A(A) do { if (fixed) SIHL_AFF(A, true); else SIHL_AFF(A, false); } while (0)
 #define SIHL_AFB(A, F) hipLaunchKernelGGL((affine_act_bwd_kernel<T, A, F>), dim3(g), dim3(TPB), 0, stream, (const T*)x, (const T*)dy, (T*)dx, nvec, C / V, scale, shift)
 #define SIHL_AFB_A(A) do { if (fixed) SIHL_AFB(A, true); else SIHL_AFB(A, false); } while (0)
+#define SIHL_NBR(M, A) hipLaunchKernelGGL((norm_bwd_reduce_kernel<T, M, A>), dim3(nblk), dim3(TPB), red_lds, stream, (const T*)s, (const T*)dy, rows, C, mean, rstd, gamma, beta, ws, rpb, nrl)
 #define SIHL_NBA(M, A, F) hipLaunchKernelGGL((norm_bwd_apply_kernel<T, M, A, F>), dim3(g), dim3(TPB), 0, stream, (const T*)s, (const T*)dy, (T*)dz, nvec, C / V, mean, rstd, gamma, beta, (const float*)sums, 1.f / (float)rows, batch_stats)
 #define SIHL_NBA_F(M, A) do { if (fixed) SIHL_NBA(M, A, true); else SIHL_NBA(M, A, false); } while (0)
 
@@ -1032,7 +1033,7 @@ int sihl_bn_finalize(const float* partials, int n_partials, int C, long count, c
                      float eps, float momentum, float* running_mean, float* running_var, float* mean, float* rstd,
                      float* scale, float* shift, hipStream_t stream) {
   if (!partials || n_partials <= 0 || C <= 0 || count <= 0 || !mean || !rstd || !scale || !shift) return SIHL_EARG;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, stream, partials, n_partials, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, stream, partials, n_partials, C,
                      (double)count, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
@@ -1267,7 +1268,7 @@ int sihl_blur_fuse_bwd(const void* dout, const void* a, const void* b, const voi
 // mode 1: s = conv (pre-norm), y = act(BN(s)).  Writes dgamma/dbeta (fp32 [C]) and dz (grad wrt conv output).
 static int reduce_blocks(long rows) {
   long nb = (rows + 255) / 256;
-  if (nb > 256) nb = 256;
+  if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
   return (int)nb;
 }
@@ -1292,9 +1293,13 @@ int sihl_norm_act_bwd(const void* s, const void* dy, void* dz, long rows, int C,
   DISPATCH_DTYPE(dtype, {
     constexpr int V = 16 / sizeof(T);
     if (C % V) return SIHL_EARG;
-    hipLaunchKernelGGL(norm_bwd_reduce_kernel<T>, dim3(nblk), dim3(TPB), (size_t)nrl * 2 * C * sizeof(float), stream,
-                       (const T*)s, (const T*)dy, rows, C, mean, rstd, gamma, beta, mode, act, ws, rpb, nrl);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, stream, (const float*)ws,
+    const size_t red_lds = (size_t)nrl * 2 * C * sizeof(float);
+    if (mode == 0) SIHL_NBR(0, SIHL_ACT_NONE);
+    else if (act == SIHL_ACT_RELU) SIHL_NBR(1, SIHL_ACT_RELU);
+    else if (act == SIHL_ACT_SILU) SIHL_NBR(1, SIHL_ACT_SILU);
+    else if (act == SIHL_ACT_SIGMOID) SIHL_NBR(1, SIHL_ACT_SIGMOID);
+    else SIHL_NBR(1, SIHL_ACT_NONE);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, stream, (const float*)ws,
                        nblk, 2, C, sums);
     const long nvec = rows * (C / V);
     bool fixed;
@@ -1362,7 +1367,7 @@ int sihl_layernorm_act_bwd(const void* z, const void* dy, void* dz, long rows, i
     if (act == SIHL_ACT_SILU) { if (cvec <= 32) SIHL_LNB(16, SIHL_ACT_SILU); else if (cvec <= 64) SIHL_LNB(32, SIHL_ACT_SILU); else SIHL_LNB(64, SIHL_ACT_SILU); }
     else { if (cvec <= 32) SIHL_LNB(16, SIHL_ACT_NONE); else if (cvec <= 64) SIHL_LNB(32, SIHL_ACT_NONE); else SIHL_LNB(64, SIHL_ACT_NONE); }
   });
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, stream, (const float*)ws, nwaves,
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, stream, (const float*)ws, nwaves,
                      2, C, sums);
   if (dbeta) { hipError_t e = hipMemcpyAsync(dbeta, sums, C * sizeof(float), hipMemcpyDeviceToDevice, stream); if (e) return (int)e; }
   if (dgamma) { hipError_t e = hipMemcpyAsync(dgamma, sums + C, C * sizeof(float), hipMemcpyDeviceToDevice, stream); if (e) return (int)e; }
@@ -1387,7 +1392,7 @@ int sihl_colsum(const void* x, long rows, int C, float* out, int dtype, float* w
       hipLaunchKernelGGL((colsum_partial_kernel<T, false>), dim3(nblk), dim3(TPB), 0, stream, (const T*)x, rows, C, ws, rpb, nrl);
     }
   });
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, stream, (const float*)ws,
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, stream, (const float*)ws,
                      nblk * nrl, 1, C, out);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
