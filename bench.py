@@ -49,9 +49,10 @@ def synthetic_batch(batch, size, device, seed):
     return images, [{"classes": classes, "boxes": boxes}]
 
 
-def build_model(ns, device):
+def build_model(ns, device, native_backbone=None):
     torch.manual_seed(0)
-    backbone = ns.ResNetBackbone("resnet50", top_level=5)
+    kw = {} if native_backbone is None else {"native": native_backbone}
+    backbone = ns.ResNetBackbone("resnet50", top_level=5, **kw)
     neck = ns.BiFPN(backbone.out_channels, 256, 3, 7, num_layers=3)
     head = ns.ObjectDetection(neck.out_channels, num_classes=80, bottom_level=3, top_level=7, num_channels=256)
     model = ns.SihlModel(backbone, neck, [head])
@@ -108,6 +109,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=4)
+    ap.add_argument("--backbone", default="torch", choices=["torch", "native"],
+                    help="torch = ResNet50 trunk on PyTorch-ROCm/MIOpen (default, fastest today); native = residual "
+                         "stages on the sihl HIP kernels")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (with --backend gloo on a one-GPU box)")
@@ -138,7 +142,7 @@ def main():
 
     hip_ns = types.SimpleNamespace(ResNetBackbone=sihl_amd.ResNetBackbone, BiFPN=sihl_amd.layers.BiFPN,
                                    ObjectDetection=sihl_amd.heads.ObjectDetection, SihlModel=sihl_amd.SihlModel)
-    model = build_model(hip_ns, device)
+    model = build_model(hip_ns, device, native_backbone=args.backbone == "native")
     amp = torch.bfloat16 if args.dtype == "bf16" else None
     trainer = Trainer(model, lr=1e-4, weight_decay=1e-4, backbone_lr_factor=0.1, grad_clip_norm=0.1,
                       autocast_dtype=amp)
@@ -195,6 +199,8 @@ def main():
                                    "fwd + bwd + grad all-reduce + clip(0.1) + AdamW, random-init weights",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "image": f"3x{args.size}x{args.size}", "parallelism": f"dp{world}",
+                       "backbone": "resnet50 trunk on " + ("sihl HIP kernels (stem on PyTorch-ROCm)"
+                                                            if args.backbone == "native" else "PyTorch-ROCm (MIOpen/CK)"),
                        "final_loss": float(loss)},
             "roofline": roofline,
         }

@@ -95,6 +95,9 @@ int sihl_bn_eval_affine(const float* gamma, const float* beta, const float* runn
 /* y = act(x*scale[c] + shift[c]) over [rows][C] (norm-apply; stand-alone SiLU / sigmoid), and its input gradient. */
 int sihl_affine_act(const void* x, void* y, long rows, int C, const float* scale, const float* shift, int act,
                     int dtype, hipStream_t stream);
+/* y = act(x*scale[c] + shift[c] + res): BatchNorm-apply + residual add + activation of a ResNet block tail. */
+int sihl_affine_add_act(const void* x, const void* res, void* y, long rows, int C, const float* scale,
+                        const float* shift, int act, int dtype, hipStream_t stream);
 int sihl_affine_act_bwd(const void* x, const void* dy, void* dx, long rows, int C, const float* scale,
                         const float* shift, int act, int dtype, hipStream_t stream);
 

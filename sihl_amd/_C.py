@@ -31,6 +31,7 @@ SIGNATURES = {
     "sihl_bn_finalize": (I, [P, I, I, L, P, P, F, F, P, P, P, P, P, P, P]),
     "sihl_bn_eval_affine": (I, [P, P, P, P, F, I, P, P, P]),
     "sihl_affine_act": (I, [P, P, L, I, P, P, I, I, P]),
+    "sihl_affine_add_act": (I, [P, P, P, L, I, P, P, I, I, P]),
     "sihl_affine_act_bwd": (I, [P, P, P, L, I, P, P, I, I, P]),
     "sihl_norm_act_bwd_ws_bytes": (L, [L, I, I]),
     "sihl_norm_act_bwd": (I, [P, P, P, L, I, P, P, P, P, P, P, I, I, I, I, P, L, P]),

@@ -4,11 +4,14 @@ torchvision's published ResNet architecture (torchvision itself is absent here),
 level contract: level 0 is the input, level 1 = ``relu`` BEFORE max-pool, levels 2..5 = ``layer1..layer4``,
 levels above 5 come from AntialiasedDownscaler blocks.  Parameter names follow torchvision's under ``model.``.
 
-Execution: the residual stages (layer1..layer4 - every 1x1 / 3x3 / strided conv + BatchNorm + ReLU + residual
-merge, forward and backward) run on the sihl HIP kernels when the input lives on a HIP device (``native``
-blocks: conv -> BN -> ReLU is the same fused conv block the FPN uses).  The 7x7 stem
-(3 input channels) + max-pool stay on PyTorch-ROCm.  On CPU tensors (BASELINE config 1, "stock PyTorch
-plumbing") the same parameters run through plain torch ops.
+Execution: by default the trunk runs on PyTorch-ROCm (MIOpen/CK), which SURVEY §8 a2 allows ("not a hand-kernel
+target").  With ``native=True`` the residual stages (layer1..layer4 - every 1x1 / 3x3 / strided conv + BatchNorm +
+ReLU + residual merge, forward and backward) run on the sihl HIP kernels instead (conv -> BN -> ReLU is the same
+fused conv block the FPN uses; the block tail is one normalise + add + ReLU pass) - SURVEY §8(f) rank 2, parity-
+tested against the oracle ResNet in tests/test_gpu_backbone.py.  Measured on the flagship step: 535 img/s native vs
+557 img/s MIOpen (round 1), so the default stays MIOpen; native removes MIOpen's ~45 s first-iteration JIT.  The 7x7
+stem (3 input channels) + max-pool stay on PyTorch-ROCm in both modes.  On CPU tensors (BASELINE config 1, "stock
+PyTorch plumbing") the same parameters run through plain torch ops.
 """
 from typing import List
 
@@ -20,13 +23,14 @@ from sihl_amd import ops
 from sihl_amd.layers.scalers import AntialiasedDownscaler
 
 
-def _conv_bn(x: Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, act, training: bool) -> Tensor:
-    """conv -> BatchNorm -> act on NHWC tensors through the fused HIP conv block (torchvision order)."""
+def _conv_bn(x: Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, act, training: bool, residual=None) -> Tensor:
+    """conv -> BatchNorm -> act on NHWC tensors through the fused HIP conv block (torchvision order); with
+    ``residual`` the block tail relu(BN(conv(x)) + residual) is one normalise+add+ReLU pass."""
     if training:
         bn.num_batches_tracked += 1
     return ops.conv_block(x, conv.weight, None, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                           stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0], act=act,
-                          order="norm_act", training=training, eps=bn.eps, momentum=bn.momentum)
+                          order="norm_act", training=training, eps=bn.eps, momentum=bn.momentum, residual=residual)
 
 
 class _Basic(nn.Module):
@@ -52,8 +56,7 @@ class _Basic(nn.Module):
         t = self.training
         idt = x if self.downsample is None else _conv_bn(x, self.downsample[0], self.downsample[1], None, t)
         y = _conv_bn(x, self.conv1, self.bn1, "relu", t)
-        y = _conv_bn(y, self.conv2, self.bn2, None, t)
-        return ops.add_relu(y, idt)
+        return _conv_bn(y, self.conv2, self.bn2, None, t, residual=idt)
 
 
 class _Bottleneck(nn.Module):
@@ -84,8 +87,7 @@ class _Bottleneck(nn.Module):
         idt = x if self.downsample is None else _conv_bn(x, self.downsample[0], self.downsample[1], None, t)
         y = _conv_bn(x, self.conv1, self.bn1, "relu", t)
         y = _conv_bn(y, self.conv2, self.bn2, "relu", t)
-        y = _conv_bn(y, self.conv3, self.bn3, None, t)
-        return ops.add_relu(y, idt)
+        return _conv_bn(y, self.conv3, self.bn3, None, t, residual=idt)
 
 
 RESNETS = {"resnet18": (_Basic, [2, 2, 2, 2]), "resnet34": (_Basic, [3, 4, 6, 3]),
@@ -132,9 +134,9 @@ class _Trunk(nn.Module):
 
 class ResNetBackbone(nn.Module):
     def __init__(self, name: str = "resnet50", pretrained: bool = False, input_channels: int = 3,
-                 top_level: int = 5, frozen_levels: int = 0, native=None):
-        """native: None = HIP residual stages whenever the input is on a HIP device (default), False = always the
-        PyTorch ops (MIOpen on ROCm), True = require the HIP path."""
+                 top_level: int = 5, frozen_levels: int = 0, native: bool = False):
+        """native: False (default) = PyTorch ops (MIOpen on ROCm); True = residual stages on the sihl HIP kernels
+        (HIP device required)."""
         super().__init__()
         self.native = native
         if name not in RESNETS:
@@ -170,7 +172,7 @@ class ResNetBackbone(nn.Module):
         assert input.shape[3] % 2 ** self.top_level == 0
         H, W = input.shape[2:]
         outs = [input]
-        native = input.is_cuda if self.native is None else bool(self.native)
+        native = bool(self.native)
         if native and not input.is_cuda:
             raise RuntimeError("native=True needs a HIP device (no CPU fallback for the HIP residual stages)")
         if native and input.dim() == 4 and not input.is_contiguous(memory_format=torch.channels_last):

@@ -114,7 +114,8 @@ template <int ACT> __device__ __forceinline__ float act_grad_c(float v) {
 // always meets the same channel vector and keeps its scale/shift in registers (FIXED = true).
 template <typename T, int ACT, bool FIXED>
 __global__ void affine_act_kernel(const T* __restrict__ x, T* __restrict__ y, long nvec, int cvec,
-                                  const float* __restrict__ scale, const float* __restrict__ shift) {
+                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                  const T* __restrict__ res) {
   constexpr int V = 16 / sizeof(T);
   float sc[V], sh[V];
   const long i0 = (long)blockIdx.x * TPB + threadIdx.x;
@@ -131,8 +132,15 @@ __global__ void affine_act_kernel(const T* __restrict__ x, T* __restrict__ y, lo
     }
     float f[V];
     ldv(x + i * V, f);
+    if (res) {  // residual merge of a ResNet block: act(BN(x) + res) in one pass
+      float r[V];
+      ldv(res + i * V, r);
 #pragma unroll
-    for (int e = 0; e < V; ++e) f[e] = act_c<ACT>(f[e] * sc[e] + sh[e]);
+      for (int e = 0; e < V; ++e) f[e] = act_c<ACT>(f[e] * sc[e] + sh[e] + r[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < V; ++e) f[e] = act_c<ACT>(f[e] * sc[e] + sh[e]);
+    }
     stv(y + i * V, f);
   }
 }
@@ -1011,7 +1019,7 @@ inline int grid_fixed(long nvec, int cvec, bool* fixed) {
 
 }  // namespace
 
-#define SIHL_AFF(A, F) hipLaunchKernelGGL((affine_act_kernel<T, A, F>), dim3(g), dim3(TPB), 0, stream, (const T*)x, (T*)y, nvec, C / V, scale, shift)
+#define SIHL_AFF(A, F) hipLaunchKernelGGL((affine_act_kernel<T, A, F>), dim3(g), dim3(TPB), 0, stream, (const T*)x, (T*)y, nvec, C / V, scale, shift, (const T*)res)
 #define SIHL_AFF_A(A) do { if (fixed) SIHL_AFF(A, true); else SIHL_AFF(A, false); } while (0)
 #define SIHL_AFB(A, F) hipLaunchKernelGGL((affine_act_bwd_kernel<T, A, F>), dim3(g), dim3(TPB), 0, stream, (const T*)x, (const T*)dy, (T*)dx, nvec, C / V, scale, shift)
 #define SIHL_AFB_A(A) do { if (fixed) SIHL_AFB(A, true); else SIHL_AFB(A, false); } while (0)
@@ -1048,8 +1056,17 @@ int sihl_bn_eval_affine(const float* gamma, const float* beta, const float* runn
   return SIHL_OK;
 }
 
+int sihl_affine_add_act(const void* x, const void* res, void* y, long rows, int C, const float* scale,
+                        const float* shift, int act, int dtype, hipStream_t stream);
+
 int sihl_affine_act(const void* x, void* y, long rows, int C, const float* scale, const float* shift, int act,
                     int dtype, hipStream_t stream) {
+  return sihl_affine_add_act(x, nullptr, y, rows, C, scale, shift, act, dtype, stream);
+}
+
+// y = act(x*scale[c] + shift[c] + res): BatchNorm-apply + residual add + activation in one pass (res may be NULL)
+int sihl_affine_add_act(const void* x, const void* res, void* y, long rows, int C, const float* scale,
+                        const float* shift, int act, int dtype, hipStream_t stream) {
   if (!x || !y || rows <= 0 || C <= 0) return SIHL_EARG;
   DISPATCH_DTYPE(dtype, {
     constexpr int V = 16 / sizeof(T);

@@ -150,6 +150,15 @@ def affine_act(x: Tensor, scale, shift, act) -> Tensor:
     return y
 
 
+def affine_add_act(x: Tensor, res: Tensor, scale, shift, act) -> Tensor:
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    rc = _C.lib().sihl_affine_add_act(_p(x), _p(res), _p(y), x.numel() // C, C, _p(scale), _p(shift), ACT[act],
+                                      _dt(x), _stream())
+    check(rc, "sihl_affine_add_act")
+    return y
+
+
 def affine_act_bwd(x: Tensor, dy: Tensor, scale, shift, act) -> Tensor:
     C = x.shape[-1]
     dx = torch.empty_like(x)
@@ -190,9 +199,10 @@ class ConvBlockFn(torch.autograd.Function):
     Conv2dNormActivation) or conv(+bias) -> act (no norm), NHWC in and out."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, cfg):
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, cfg, residual=None):
         stride, pad, dil, act, order, has_norm, training, eps, momentum, need_grad = cfg
         xd = x.detach()
+        ctx.has_res = residual is not None
         w = weight_khwc(weight, xd.dtype)
         KH, KW = w.shape[1], w.shape[2]
         ctx.cfg, ctx.has_norm, ctx.kshape = cfg, has_norm, (KH, KW)
@@ -218,6 +228,11 @@ class ConvBlockFn(torch.autograd.Function):
             count = s.numel() // s.shape[-1]
             mean, rstd, scale, shift = bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean,
                                                    running_var)
+            if residual is not None:  # block tail: y = relu(BN(conv) + identity) in one pass; keep y for the mask
+                y = affine_add_act(s, residual.detach().contiguous(), scale, shift, "relu")
+                ctx.save_for_backward(xd, w, s, mean, rstd, gamma.detach(), beta.detach(), y)
+                ctx.batch_stats, ctx.kind = True, "norm"
+                return y
             y = affine_act(s, scale, shift, None if mode == 0 else act)
             ctx.batch_stats = True
         else:
@@ -244,7 +259,12 @@ class ConvBlockFn(torch.autograd.Function):
         KH, KW = ctx.kshape
         dy = dy.contiguous()
         dgamma = dbeta = None
-        if ctx.kind == "norm":
+        dres = None
+        if ctx.kind == "norm" and ctx.has_res:
+            x, w, s, mean, rstd, gamma, beta, y = ctx.saved_tensors
+            dres = affine_act_bwd(y, dy, None, None, "relu")  # dy * (y > 0): gradient of both merge inputs
+            dz, dgamma, dbeta = norm_act_bwd(s, dres, mean, rstd, gamma, beta, 1, None, ctx.batch_stats)
+        elif ctx.kind == "norm":
             x, w, s, mean, rstd, gamma, beta = ctx.saved_tensors
             dz, dgamma, dbeta = norm_act_bwd(s, dy, mean, rstd, gamma, beta, ctx.mode, act, ctx.batch_stats)
         elif ctx.kind == "split_act":
@@ -264,17 +284,26 @@ class ConvBlockFn(torch.autograd.Function):
             rc = _C.lib().sihl_conv2d_dgrad(_p(dz), _p(wt), _p(dx), N, H, W, Cin, w.shape[0], KH, KW, stride, pad,
                                             dil, _dt(x), _stream())
             check(rc, "sihl_conv2d_dgrad")
-        return dx, dw, dbias, dgamma, dbeta, None, None, None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, dres
 
 
 def conv_block(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, *, stride=1, pad=0, dil=1, act=None,
-               order="act_norm", training=False, eps=1e-5, momentum=0.1):
+               order="act_norm", training=False, eps=1e-5, momentum=0.1, residual=None):
+    """residual (optional, order "norm_act" only): the block computes relu(BN(conv(x)) + residual)."""
     has_norm = running_mean is not None
     # autograd.Function.forward always runs with grad mode off, so decide here whether a backward can follow
     need_grad = torch.is_grad_enabled() and any(
         t is not None and t.requires_grad for t in (x_nhwc, weight, bias, gamma, beta))
     cfg = (stride, pad, dil, act, order, has_norm, training, eps, momentum, need_grad)
-    return ConvBlockFn.apply(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, cfg)
+    if residual is None:
+        return ConvBlockFn.apply(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, cfg)
+    if order != "norm_act" or not has_norm or act is not None:
+        raise ValueError("residual merge is defined for conv -> BatchNorm (no activation) blocks")
+    if training:
+        need_grad = need_grad or (torch.is_grad_enabled() and residual.requires_grad)
+        cfg = (stride, pad, dil, act, order, has_norm, training, eps, momentum, need_grad)
+        return ConvBlockFn.apply(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, cfg, residual)
+    return add_relu(ConvBlockFn.apply(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, cfg), residual)
 
 
 # ----------------------------------------------------------------------------- fusion nodes
