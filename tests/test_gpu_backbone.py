@@ -77,7 +77,7 @@ def test_native_backbone_bf16_close():
     import sihl_amd
 
     torch.manual_seed(0)
-    m = sihl_amd.ResNetBackbone("resnet50").cuda().eval()
+    m = sihl_amd.ResNetBackbone("resnet50", native=True).cuda().eval()
     x = torch.rand(2, 3, 128, 128, device="cuda").contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
         ref = m(x)  # fp32 native
