@@ -5,7 +5,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from sihl_amd import ops  # noqa: E402
 
 dev, dt = "cuda", torch.bfloat16

@@ -60,7 +60,7 @@ def test_native_backbone_fp32_matches_oracle(name, size, train):
         rms = float(err.pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp(min=1e-12))
         stem = n == "input" or n.startswith("model.conv1") or n.startswith("model.bn1")
         worst["stem" if stem else "stages"] = max(worst.get("stem" if stem else "stages", 0.0), rms)
-        # Measured three ways on resnet50 @128 (tests/golden/bb_debug.py): PyTorch-GPU(MIOpen) vs PyTorch-CPU differ
+        # Measured three ways on resnet50 @128 (tools/bb_debug.py): PyTorch-GPU(MIOpen) vs PyTorch-CPU differ
         # by 2.1-2.5e-3 rms on early-layer gradients, the HIP path by 3.2-4.5e-3 from CPU and 2.5-3.4e-3 from
         # PyTorch-GPU, while the last block agrees to 1e-6 everywhere: one flipped ReLU mask among layer4's 65k
         # elements moves every upstream gradient by ~1/sqrt(65k) = 4e-3.  Bound = that noise floor with margin.

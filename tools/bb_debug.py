@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import oracle, sihl_amd
 name, size, train = "resnet50", int(sys.argv[1]) if len(sys.argv) > 1 else 128, False
 torch.manual_seed(0)

@@ -1,5 +1,5 @@
 import time, torch, sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import sihl_amd
 def log(*a):
     print(*a, flush=True)

@@ -1,13 +1,14 @@
 """Developer diagnostic (GPU box): per-tensor error of the HIP path vs the golden vectors (fp32) and vs
-the fp32 oracle evaluated at bf16-rounded operands (bf16).  Usage: python tests/golden/diag.py case..."""
+the fp32 oracle evaluated at bf16-rounded operands (bf16).  Usage: python tools/diag.py case..."""
 import os
 import sys
 
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, HERE)
-sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+sys.path.insert(0, ROOT)
 from cases import CASES  # noqa: E402
 from util import golden_results, load_npz, namespace_of, quantized_copy, replay  # noqa: E402
 

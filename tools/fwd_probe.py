@@ -4,7 +4,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import sihl_amd  # noqa: E402
 
 CH = [3, 64, 256, 512, 1024, 2048]
