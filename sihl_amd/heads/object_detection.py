@@ -91,15 +91,19 @@ class ObjectDetection(nn.Module):
     # ------------------------------------------------------------------ training
     def training_step(self, inputs: List[Tensor], classes: List[Tensor], boxes: List[Tensor],
                       is_validating: bool = False) -> Tuple[Tensor, Dict[str, float]]:
+        """Loss of the reference (:124-217), arranged so that the host never waits for the device: no boolean-mask
+        indexing / nonzero / `.max() == 0` branch / pageable host->device copy.  The one-to-many rows (reference
+        `rel_iou > 0`, :183-208) are enumerated as the fixed-size candidate list (image, ground truth, rank <
+        topk) of the matching itself, each weighted by rel_iou when the anchor's assigned ground truth is that
+        one and by exactly 0 otherwise - the same weighted sums over the same rows, in a different order."""
         assert len(inputs) > self.top_level, "too few input levels"
         device = inputs[self.bottom_level].device
         B, _, H, W = inputs[0].shape
-        full = torch.tensor([[W, H, W, H]], device=device, dtype=torch.float32)
+        full = self._full_size(W, H, device)
         offsets, scales = self.get_offsets_and_scales(inputs)
         anchors = (offsets + scales) * full
-        boxes = [b.to(device) for b in boxes]
-        classes = [c.to(device) for c in classes]
-        assignment, rel_iou = self.batched_matching(anchors, boxes, self.topk)
+        gt, gt_cls, col_ok = self._pad_targets(boxes, classes, device)
+        assignment, rel_iou, top_i = self._match_padded(anchors, gt, col_ok, self.topk)
 
         flat = self._flat_feats(inputs)
         P, C = flat.shape[1], flat.shape[2]
@@ -107,67 +111,77 @@ class ObjectDetection(nn.Module):
         loc_target = (rel_iou == 1.0).to(torch.float32)
         loc_loss = F.binary_cross_entropy_with_logits(loc_logits.float(), loc_target, reduction="none")
         loc_loss = loc_loss.sum() / loc_target.sum()
-        if rel_iou.max() == 0:
-            z = torch.zeros_like(loc_loss)
+        z = torch.zeros_like(loc_loss)
+        if gt.shape[1] == 0:  # no ground truth in the whole batch (host-side shapes): reference early-out :165-172
             return loc_loss, {"location_loss": loc_loss, "box_loss": z, "class_loss": z, "iou_loss": z}
 
         iou_preds = self.iou_head(flat.view(B * P, C)).reshape(B, P)
         iou_loss = F.mse_loss(iou_preds.float(), rel_iou, reduction="none").sum() / rel_iou.sum()
 
-        mask = rel_iou > 0
-        wts = rel_iou[mask]
-        sel = flat[mask]
-        pos = mask.nonzero()  # (n, 2): image, position - same row-major order as boolean indexing
-        off_sel, scl_sel = offsets[pos[:, 1]], scales[pos[:, 1]]
-        gt_idx = assignment[mask]
-        gt_off = torch.tensor([0] + [len(b) for b in boxes[:-1]], device=device).cumsum(0)
-        flat_gt = gt_off[pos[:, 0]] + gt_idx
-        all_boxes = torch.cat(boxes).to(torch.float32)
-        all_classes = torch.cat(classes)
+        G, K = gt.shape[1], top_i.shape[1]
+        cand = top_i.permute(0, 2, 1).reshape(B, G * K)  # anchor index of candidate (image, gt, rank)
+        cand_gt = torch.arange(G, device=device).repeat_interleave(K)[None, :].expand(B, -1)
+        mine = (torch.gather(assignment, 1, cand) == cand_gt) & col_ok.repeat_interleave(K, dim=1)
+        wts = (torch.gather(rel_iou, 1, cand) * mine).reshape(-1)  # 0 for rows the reference does not select
+        rows = (cand + torch.arange(B, device=device)[:, None] * P).reshape(-1)
+        sel = torch.index_select(flat.view(B * P, C), 0, rows)
+        anchor_of = cand.reshape(-1)
+        tgt_box = torch.gather(gt, 1, cand_gt[..., None].expand(-1, -1, 4)).reshape(-1, 4) / full
+        tgt_cls = torch.gather(gt_cls, 1, cand_gt).reshape(-1)
+        wsum = wts.sum()
 
-        box_preds = off_sel + scl_sel * self.box_head(sel).float().exp()
-        box_loss = complete_box_iou_loss(box_preds, all_boxes[flat_gt] / full)
-        box_loss = (wts * box_loss).sum() / wts.sum()
+        box_preds = offsets[anchor_of] + scales[anchor_of] * self.box_head(sel).float().exp()
+        box_loss = (wts * complete_box_iou_loss(box_preds, tgt_box)).sum() / wsum
 
-        cls_logits = self.cls_head(sel)
-        cls_loss = F.cross_entropy(cls_logits.float(), all_classes[flat_gt], reduction="none")
-        cls_loss = (wts * cls_loss).sum() / wts.sum()
+        cls_loss = F.cross_entropy(self.cls_head(sel).float(), tgt_cls, reduction="none")
+        cls_loss = (wts * cls_loss).sum() / wsum
 
-        loss = loc_loss + 10 * box_loss + cls_loss + iou_loss
-        return loss, {"location_loss": loc_loss, "box_loss": box_loss, "class_loss": cls_loss,
-                      "iou_loss": iou_loss}
+        none_matched = rel_iou.max() == 0  # degenerate ground truths only; stays on the device
+        pick = lambda t: torch.where(none_matched, z, t)  # noqa: E731
+        loss = torch.where(none_matched, loc_loss, loc_loss + 10 * box_loss + cls_loss + iou_loss)
+        return loss, {"location_loss": loc_loss, "box_loss": pick(box_loss), "class_loss": pick(cls_loss),
+                      "iou_loss": pick(iou_loss)}
 
-    def on_validation_start(self) -> None:
-        self._val_losses: List[Tensor] = []
-
-    def validation_step(self, inputs, classes, boxes):
-        loss, metrics = self.training_step(inputs, classes, boxes, is_validating=True)
-        self._val_losses.append(loss.detach())
-        return loss, metrics
-
-    def on_validation_end(self) -> Dict[str, float]:
-        # box mAP needs a COCO evaluator (torchmetrics + faster_coco_eval in the reference): out of scope
-        return {"loss": torch.stack(self._val_losses).mean().item() if self._val_losses else float("nan")}
+    def _full_size(self, W: int, H: int, device) -> Tensor:
+        """(1, 4) tensor (W, H, W, H), uploaded once per image size (an upload from pageable memory blocks the host
+        until the stream has drained)."""
+        key = (W, H, str(device))
+        cache = self.__dict__.setdefault("_full_cache", {})
+        if key not in cache:
+            cache[key] = torch.tensor([[W, H, W, H]], device=device, dtype=torch.float32)
+        return cache[key]
 
     @staticmethod
-    def batched_matching(anchors: Tensor, boxes: List[Tensor], topk: int) -> Tuple[Tensor, Tensor]:
-        """bbox_matching(relative=True) for the whole batch at once: ground truths are zero-padded to the
-        batch maximum and padded columns are masked out, so the result per image equals the per-image routine
-        of the reference (:143-148, :252-284) while launching ~30 kernels instead of ~30 per image."""
-        B, A = len(boxes), anchors.shape[0]
-        counts = [int(b.shape[0]) for b in boxes]  # host-side shapes: no device sync
-        G = max(counts) if counts else 0
-        device = anchors.device
+    def _pad_targets(boxes: List[Tensor], classes: List[Tensor], device) -> Tuple[Tensor, Tensor, Tensor]:
+        """Per-image target lists -> (B, G, 4) boxes, (B, G) classes, (B, G) validity, G = batch maximum.
+        Padding is marked with NaN boxes so validity is derived on the device (no count upload); padded slots then
+        get a degenerate-free placeholder box that keeps the CIoU arithmetic finite."""
+        B = len(boxes)
+        G = max([int(b.shape[0]) for b in boxes], default=0)  # host-side shapes: no device sync
+        if G == 0:
+            return (torch.zeros((B, 0, 4), device=device), torch.zeros((B, 0), device=device, dtype=torch.int64),
+                    torch.zeros((B, 0), device=device, dtype=torch.bool))
+        pad = torch.nn.utils.rnn.pad_sequence
+        gt = pad([b.to(device=device, dtype=torch.float32).reshape(-1, 4) for b in boxes], batch_first=True,
+                 padding_value=float("nan"))
+        cls = pad([c.to(device=device, dtype=torch.int64).reshape(-1) for c in classes], batch_first=True)
+        col_ok = ~gt[..., 0].isnan()
+        placeholder = torch.zeros_like(gt)
+        placeholder[..., 2:] = 1.0
+        return torch.where(col_ok[..., None], gt, placeholder), cls, col_ok
+
+    @staticmethod
+    def _match_padded(anchors: Tensor, gt: Tensor, col_ok: Tensor, topk: int) -> Tuple[Tensor, Tensor, Tensor]:
+        """bbox_matching(relative=True) for the whole batch at once on padded ground truths: padded columns are
+        masked out, so the result per image equals the per-image routine of the reference (:143-148, :252-284)
+        while launching ~30 kernels instead of ~30 per image.  Also returns the per-(image, gt) top-k anchor
+        indices (B, k, G)."""
+        B, G = gt.shape[:2]
+        A, device = anchors.shape[0], anchors.device
         if G == 0:
             return (torch.full((B, A), -1, device=device, dtype=torch.int64),
-                    torch.zeros((B, A), device=device, dtype=torch.float32))
-        gt = torch.zeros((B, G, 4), device=device, dtype=torch.float32)
-        # a degenerate-free placeholder box for padded slots keeps the CIoU arithmetic finite
-        gt[..., 2:] = 1.0
-        for b, bx in enumerate(boxes):
-            if counts[b]:
-                gt[b, : counts[b]] = bx.to(torch.float32)
-        col_ok = torch.arange(G, device=device)[None, :] < torch.tensor(counts, device=device)[:, None]  # (B, G)
+                    torch.zeros((B, A), device=device, dtype=torch.float32),
+                    torch.zeros((B, topk, 0), device=device, dtype=torch.int64))
         ious = complete_box_iou(anchors, gt.reshape(B * G, 4)).reshape(A, B, G).permute(1, 0, 2).clamp(0)
         ious = ious * col_ok[:, None, :]
         top_v, top_i = torch.topk(ious, k=topk, dim=1)  # (B, k, G)
@@ -179,7 +193,14 @@ class ObjectDetection(nn.Module):
         assign = torch.where(valid, best_gt, torch.full_like(best_gt, -1))
         denom = torch.gather(top_v[:, 0, :], 1, best_gt)
         rel = (best_iou / denom).nan_to_num(0)
-        return assign, torch.where(valid, rel, torch.zeros_like(rel))
+        return assign, torch.where(valid, rel, torch.zeros_like(rel)), top_i
+
+    @classmethod
+    def batched_matching(cls, anchors: Tensor, boxes: List[Tensor], topk: int) -> Tuple[Tensor, Tensor]:
+        """(assignment, rel_iou), each (B, A), for per-image ground-truth lists."""
+        gt, _, col_ok = cls._pad_targets(boxes, [b.new_zeros(b.shape[0], dtype=torch.int64) for b in boxes],
+                                         anchors.device)
+        return cls._match_padded(anchors, gt, col_ok, topk)[:2]
 
     @staticmethod
     def bbox_matching(anchors: Tensor, gt_boxes: Tensor, topk: int, relative: bool = False):
@@ -200,3 +221,15 @@ class ObjectDetection(nn.Module):
             return assign, torch.where(valid, best_iou, o2m)
         rel = (best_iou / top_v[0][best_gt]).nan_to_num(0)
         return assign, torch.where(valid, rel, o2m)
+
+    def on_validation_start(self) -> None:
+        self._val_losses: List[Tensor] = []
+
+    def validation_step(self, inputs, classes, boxes):
+        loss, metrics = self.training_step(inputs, classes, boxes, is_validating=True)
+        self._val_losses.append(loss.detach())
+        return loss, metrics
+
+    def on_validation_end(self) -> Dict[str, float]:
+        # box mAP needs a COCO evaluator (torchmetrics + faster_coco_eval in the reference): out of scope
+        return {"loss": torch.stack(self._val_losses).mean().item() if self._val_losses else float("nan")}
