@@ -150,7 +150,7 @@ int sihl_add_act(const void* a, const void* b, void* out, long numel, int act, i
 /* ---- MLP hidden layers: y = act(LayerNorm(z)*gamma + beta) over [rows][C] (object_detection.py:51-61) ----- */
 int sihl_layernorm_act(const void* z, void* y, long rows, int C, const float* gamma, const float* beta, float eps,
                        int act, float* mean, float* rstd, int dtype, hipStream_t stream);
-int sihl_layernorm_bwd_waves(long rows);
+int sihl_layernorm_bwd_waves(long rows); /* workgroups = partial rows of the backward (workspace sizing) */
 long sihl_layernorm_act_bwd_ws_bytes(long rows, int C);
 int sihl_layernorm_act_bwd(const void* z, const void* dy, void* dz, long rows, int C, const float* gamma,
                            const float* beta, const float* mean, const float* rstd, int act, float* dgamma,

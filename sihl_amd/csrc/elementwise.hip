@@ -19,6 +19,21 @@ template <typename T> __device__ __forceinline__ void ldv(const T* p, float (&f)
 template <typename T> __device__ __forceinline__ void stv(T* p, const float (&f)[16 / sizeof(T)]) {
   *(uint4*)p = pack16(f, T());
 }
+// V consecutive per-channel fp32 parameters starting at channel c (c % 4 == 0, arrays 16-byte aligned) as 16-byte
+// loads that are all issued before the first use; a NULL array yields the default.  (Element-wise `p ? p[c+e] : d`
+// compiles to V dependent load/wait round trips - a serial prologue of several microseconds per wave.)
+template <int V> __device__ __forceinline__ void ldparam(const float* __restrict__ p, int c, float (&out)[V], float dflt) {
+  if (p) {
+#pragma unroll
+    for (int k = 0; k < V / 4; ++k) {
+      const float4 t = *(const float4*)(p + c + 4 * k);
+      out[4 * k] = t.x; out[4 * k + 1] = t.y; out[4 * k + 2] = t.z; out[4 * k + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < V; ++e) out[e] = dflt;
+  }
+}
 
 __device__ __forceinline__ void softmax_w(const float* raw, int n, float (&w)[3]) {
   w[0] = w[1] = w[2] = 0.f;
@@ -97,16 +112,22 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
 }
 
 // ------------------------------------------------------------------ y = act(x*scale[c] + shift[c])
+// sigmoid with the hardware exp2 / reciprocal instructions (1 ulp each): two quarter-rate transcendentals instead of
+// the ~40-instruction expf + IEEE division, which made the SiLU kernels VALU-bound instead of HBM-bound.
+__device__ __forceinline__ float fast_sigmoid(float v) {
+  const float e = __builtin_amdgcn_exp2f(fminf(-v * 1.4426950408889634f, 126.f));
+  return __builtin_amdgcn_rcpf(1.f + e);
+}
 template <int ACT> __device__ __forceinline__ float act_c(float v) {
   if (ACT == SIHL_ACT_RELU) return fmaxf(v, 0.f);
-  if (ACT == SIHL_ACT_SILU) return v / (1.f + expf(-v));
-  if (ACT == SIHL_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+  if (ACT == SIHL_ACT_SILU) return v * fast_sigmoid(v);
+  if (ACT == SIHL_ACT_SIGMOID) return fast_sigmoid(v);
   return v;
 }
 template <int ACT> __device__ __forceinline__ float act_grad_c(float v) {
   if (ACT == SIHL_ACT_RELU) return v > 0.f ? 1.f : 0.f;
-  if (ACT == SIHL_ACT_SILU) { const float s = 1.f / (1.f + expf(-v)); return s * (1.f + v * (1.f - s)); }
-  if (ACT == SIHL_ACT_SIGMOID) { const float s = 1.f / (1.f + expf(-v)); return s * (1.f - s); }
+  if (ACT == SIHL_ACT_SILU) { const float s = fast_sigmoid(v); return s * (1.f + v * (1.f - s)); }
+  if (ACT == SIHL_ACT_SIGMOID) { const float s = fast_sigmoid(v); return s * (1.f - s); }
   return 1.f;
 }
 
@@ -121,14 +142,14 @@ __global__ void affine_act_kernel(const T* __restrict__ x, T* __restrict__ y, lo
   const long i0 = (long)blockIdx.x * TPB + threadIdx.x;
   if (FIXED) {
     const int c = (int)(i0 % cvec) * V;
-#pragma unroll
-    for (int e = 0; e < V; ++e) { sc[e] = scale ? scale[c + e] : 1.f; sh[e] = (scale && shift) ? shift[c + e] : 0.f; }
+    ldparam<V>(scale, c, sc, 1.f);
+    ldparam<V>(scale ? shift : nullptr, c, sh, 0.f);
   }
   for (long i = i0; i < nvec; i += (long)gridDim.x * TPB) {
     if (!FIXED) {
       const int c = (int)(i % cvec) * V;
-#pragma unroll
-      for (int e = 0; e < V; ++e) { sc[e] = scale ? scale[c + e] : 1.f; sh[e] = (scale && shift) ? shift[c + e] : 0.f; }
+      ldparam<V>(scale, c, sc, 1.f);
+      ldparam<V>(scale ? shift : nullptr, c, sh, 0.f);
     }
     float f[V];
     ldv(x + i * V, f);
@@ -154,14 +175,14 @@ __global__ void affine_act_bwd_kernel(const T* __restrict__ x, const T* __restri
   const long i0 = (long)blockIdx.x * TPB + threadIdx.x;
   if (FIXED) {
     const int c = (int)(i0 % cvec) * V;
-#pragma unroll
-    for (int e = 0; e < V; ++e) { sc[e] = scale ? scale[c + e] : 1.f; sh[e] = (scale && shift) ? shift[c + e] : 0.f; }
+    ldparam<V>(scale, c, sc, 1.f);
+    ldparam<V>(scale ? shift : nullptr, c, sh, 0.f);
   }
   for (long i = i0; i < nvec; i += (long)gridDim.x * TPB) {
     if (!FIXED) {
       const int c = (int)(i % cvec) * V;
-#pragma unroll
-      for (int e = 0; e < V; ++e) { sc[e] = scale ? scale[c + e] : 1.f; sh[e] = (scale && shift) ? shift[c + e] : 0.f; }
+      ldparam<V>(scale, c, sc, 1.f);
+      ldparam<V>(scale ? shift : nullptr, c, sh, 0.f);
     }
     float f[V], g[V];
     ldv(x + i * V, f);
@@ -701,12 +722,10 @@ __global__ void norm_bwd_reduce_kernel(const T* __restrict__ s, const T* __restr
 #pragma unroll
     for (int e = 0; e < V; ++e) sb[e] = sg[e] = 0.f;
     float mu[V], rs[V], ga[V], be[V];
-#pragma unroll
-    for (int e = 0; e < V; ++e) {
-      const int c = cv * V + e;
-      mu[e] = mean[c]; rs[e] = rstd[c];
-      ga[e] = gamma ? gamma[c] : 1.f; be[e] = beta ? beta[c] : 0.f;
-    }
+    ldparam<V>(mean, cv * V, mu, 0.f);
+    ldparam<V>(rstd, cv * V, rs, 1.f);
+    ldparam<V>(MODE == 1 ? gamma : nullptr, cv * V, ga, 1.f);
+    ldparam<V>(MODE == 1 ? beta : nullptr, cv * V, be, 0.f);
     for (long r = r0 + rl; r < r1; r += nrl) {
       float fs[V], fd[V];
       ldv(s + (r * cvec + cv) * V, fs);
@@ -738,7 +757,8 @@ __global__ void norm_bwd_reduce_kernel(const T* __restrict__ s, const T* __restr
 // out[k][c] = sum_r part[r][k][c]   (k < K).  256 threads = 4 columns x 64 row lanes: fp32 partials are summed in
 // double per lane, the 64 lanes are combined through LDS (grid = K*C/4 workgroups, so even 64-channel layers
 // spread over 32+ CUs).
-__global__ void colsum_finalize_kernel(const float* __restrict__ part, int R, int K, int C, float* __restrict__ out) {
+__global__ void colsum_finalize_kernel(const float* __restrict__ part, int R, int K, int C, float* __restrict__ out0,
+                                       float* __restrict__ out1) {
   __shared__ double sh[64][5];
   const int cx = threadIdx.x & 3, ry = threadIdx.x >> 2;
   const int idx = blockIdx.x * 4 + cx, KC = K * C;
@@ -756,7 +776,7 @@ __global__ void colsum_finalize_kernel(const float* __restrict__ part, int R, in
   if (ry == 0 && idx < KC) {
     double t = 0.0;
     for (int k = 0; k < 64; ++k) t += sh[k][cx];
-    out[idx] = (float)t;
+    if (idx < C) out0[idx] = (float)t; else out1[idx - C] = (float)t;  // K <= 2: row 0 -> out0, row 1 -> out1
   }
 }
 
@@ -765,20 +785,21 @@ template <typename T, int MODE, int ACT, bool FIXED>
 __global__ void norm_bwd_apply_kernel(const T* __restrict__ s, const T* __restrict__ dy, T* __restrict__ dz, long nvec,
                                       int cvec, const float* __restrict__ mean, const float* __restrict__ rstd,
                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                      const float* __restrict__ sums /*[2][C]: dbeta, dgamma*/, float inv_count,
+                                      const float* __restrict__ sum_g /*dbeta*/, const float* __restrict__ sum_gx /*dgamma*/,
+                                      float inv_count,
                                       int batch_stats) {
   constexpr int V = 16 / sizeof(T);
   const int C = cvec * V;
   float mu[V], rs[V], ga[V], be[V], k0[V], k1[V];
   auto load_params = [&](int c0) {
+    ldparam<V>(mean, c0, mu, 0.f);
+    ldparam<V>(rstd, c0, rs, 1.f);
+    ldparam<V>(gamma, c0, ga, 1.f);
+    ldparam<V>(MODE == 1 ? beta : nullptr, c0, be, 0.f);
+    ldparam<V>(batch_stats ? sum_g : nullptr, c0, k0, 0.f);
+    ldparam<V>(batch_stats ? sum_gx : nullptr, c0, k1, 0.f);
 #pragma unroll
-    for (int e = 0; e < V; ++e) {
-      const int c = c0 + e;
-      mu[e] = mean[c]; rs[e] = rstd[c];
-      ga[e] = gamma ? gamma[c] : 1.f; be[e] = beta ? beta[c] : 0.f;
-      k0[e] = batch_stats ? inv_count * sums[c] : 0.f;
-      k1[e] = batch_stats ? inv_count * sums[C + c] : 0.f;
-    }
+    for (int e = 0; e < V; ++e) { k0[e] *= inv_count; k1[e] *= inv_count; }
   };
   const long i0 = (long)blockIdx.x * TPB + threadIdx.x;
   if (FIXED) load_params((int)(i0 % cvec) * V);
@@ -801,58 +822,59 @@ __global__ void norm_bwd_apply_kernel(const T* __restrict__ s, const T* __restri
 }
 
 // ------------------------------------------------------------------ LayerNorm + activation over rows of C
-// SUB lanes cooperate on one row (64/SUB rows per wave); a lane owns 16-byte chunks sub and sub+SUB (C <= 2*SUB*V).
+// SUB lanes cooperate on one row (64/SUB rows per wave); a lane owns NK 16-byte chunks: sub, sub+SUB, ...
+// (C <= NK*SUB*V).  NK = 1 whenever the row fits (256 bf16 channels = 32 lanes x 8): half the live registers of the
+// two-chunk form, which spilled in the backward kernel.
 template <int SUB> __device__ __forceinline__ float sub_sum(float v) {
 #pragma unroll
   for (int o = SUB / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
 
-template <typename T, int SUB, int ACT>
-__global__ void layernorm_act_kernel(const T* __restrict__ z, T* __restrict__ y, long rows, int C,
-                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                     float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+template <typename T, int SUB, int NK, int ACT>
+__global__ void __launch_bounds__(TPB)
+layernorm_act_kernel(const T* __restrict__ z, T* __restrict__ y, long rows, int C, const float* __restrict__ gamma,
+                     const float* __restrict__ beta, float eps, float* __restrict__ mean_out,
+                     float* __restrict__ rstd_out) {
   constexpr int V = 16 / sizeof(T), RPW = 64 / SUB;
   const int cvec = C / V, lane = threadIdx.x & 63, sub = lane % SUB, rsel = lane / SUB;
   const long wave = ((long)blockIdx.x * TPB + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * TPB) >> 6;
-  float ga[2][V], be[2][V];
+  const float inv_c = 1.f / (float)C;
+  float ga[NK][V], be[NK][V];
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < NK; ++k) {
     const int cv = sub + SUB * k;
-#pragma unroll
-    for (int e = 0; e < V; ++e) {
-      ga[k][e] = cv < cvec ? gamma[cv * V + e] : 0.f;
-      be[k][e] = cv < cvec ? beta[cv * V + e] : 0.f;
-    }
+    ldparam<V>(cv < cvec ? gamma : nullptr, cv * V, ga[k], 0.f);
+    ldparam<V>(cv < cvec ? beta : nullptr, cv * V, be[k], 0.f);
   }
   for (long r0 = wave * RPW; r0 < rows; r0 += nwaves * RPW) {
     const long r = r0 + rsel;
     const bool rok = r < rows;
-    float f[2][V];
+    float f[NK][V];
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NK; ++k) {
       const int cv = sub + SUB * k;
 #pragma unroll
       for (int e = 0; e < V; ++e) f[k][e] = 0.f;
-      if (rok && cv < cvec) {
-        ldv(z + (r * cvec + cv) * V, f[k]);
-#pragma unroll
-        for (int e = 0; e < V; ++e) s += f[k][e];
-      }
+      if (rok && cv < cvec) ldv(z + (r * cvec + cv) * V, f[k]);
     }
-    const float mu = sub_sum<SUB>(s) / C;
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+      for (int e = 0; e < V; ++e) s += f[k][e];
+    const float mu = sub_sum<SUB>(s) * inv_c;
     float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < NK; ++k)
       if (sub + SUB * k < cvec) {
 #pragma unroll
         for (int e = 0; e < V; ++e) { const float d = f[k][e] - mu; q += d * d; }
       }
-    const float rs = 1.f / sqrtf(sub_sum<SUB>(q) / C + eps);
+    const float rs = 1.f / sqrtf(sub_sum<SUB>(q) * inv_c + eps);
     if (rok && sub == 0 && mean_out) { mean_out[r] = mu; rstd_out[r] = rs; }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NK; ++k) {
       const int cv = sub + SUB * k;
       if (rok && cv < cvec) {
 #pragma unroll
@@ -864,58 +886,58 @@ __global__ void layernorm_act_kernel(const T* __restrict__ z, T* __restrict__ y,
 }
 
 // dz = rstd * (gh - mean_c(gh) - xhat * mean_c(gh*xhat)), gh = dy*act'(u)*gamma ; per-wave column partials
-// part: [nwaves][2][C] (dbeta, dgamma)
-template <typename T, int SUB, int ACT>
-__global__ void layernorm_act_bwd_kernel(const T* __restrict__ z, const T* __restrict__ dy, T* __restrict__ dz,
-                                         long rows, int C, const float* __restrict__ gamma,
-                                         const float* __restrict__ beta, const float* __restrict__ mean,
-                                         const float* __restrict__ rstd, float* __restrict__ part) {
+// part: [gridDim.x][2][C] (dbeta, dgamma), the workgroup's waves folded through LDS
+template <typename T, int SUB, int NK, int ACT>
+__global__ void __launch_bounds__(TPB)
+layernorm_act_bwd_kernel(const T* __restrict__ z, const T* __restrict__ dy, T* __restrict__ dz, long rows, int C,
+                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                         const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ part) {
   constexpr int V = 16 / sizeof(T), RPW = 64 / SUB;
   const int cvec = C / V, lane = threadIdx.x & 63, sub = lane % SUB, rsel = lane / SUB;
   const long wave = ((long)blockIdx.x * TPB + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * TPB) >> 6;
-  float pb[2][V], pg[2][V], ga[2][V], be[2][V];
+  const float inv_c = 1.f / (float)C;
+  float pb[NK][V], pg[NK][V], ga[NK][V], be[NK][V];
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < NK; ++k) {
     const int cv = sub + SUB * k;
 #pragma unroll
-    for (int e = 0; e < V; ++e) {
-      pb[k][e] = pg[k][e] = 0.f;
-      ga[k][e] = cv < cvec ? gamma[cv * V + e] : 0.f;
-      be[k][e] = cv < cvec ? beta[cv * V + e] : 0.f;
-    }
+    for (int e = 0; e < V; ++e) pb[k][e] = pg[k][e] = 0.f;
+    ldparam<V>(cv < cvec ? gamma : nullptr, cv * V, ga[k], 0.f);
+    ldparam<V>(cv < cvec ? beta : nullptr, cv * V, be[k], 0.f);
   }
   for (long r0 = wave * RPW; r0 < rows; r0 += nwaves * RPW) {
     const long r = r0 + rsel;
     const bool rok = r < rows;
-    const float mu = rok ? mean[r] : 0.f, rs = rok ? rstd[r] : 0.f;
-    float xh[2][V], gh[2][V];
-    float s1 = 0.f, s2 = 0.f;
+    float xh[NK][V], gh[NK][V];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NK; ++k) {  // issue every load of the row group before the first use
       const int cv = sub + SUB * k;
 #pragma unroll
       for (int e = 0; e < V; ++e) xh[k][e] = gh[k][e] = 0.f;
       if (rok && cv < cvec) {
-        float fz[V], fd[V];
-        ldv(z + (r * cvec + cv) * V, fz);
-        ldv(dy + (r * cvec + cv) * V, fd);
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-          const float x = (fz[e] - mu) * rs;
-          const float g = fd[e] * act_grad_c<ACT>(x * ga[k][e] + be[k][e]);
-          pb[k][e] += g;
-          pg[k][e] += g * x;
-          xh[k][e] = x;
-          gh[k][e] = g * ga[k][e];
-          s1 += gh[k][e];
-          s2 += gh[k][e] * x;
-        }
+        ldv(z + (r * cvec + cv) * V, xh[k]);
+        ldv(dy + (r * cvec + cv) * V, gh[k]);
       }
     }
-    s1 = sub_sum<SUB>(s1) / C;
-    s2 = sub_sum<SUB>(s2) / C;
+    const float mu = rok ? mean[r] : 0.f, rs = rok ? rstd[r] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float x = (xh[k][e] - mu) * rs;
+        const float g = gh[k][e] * act_grad_c<ACT>(x * ga[k][e] + be[k][e]);
+        pb[k][e] += g;
+        pg[k][e] += g * x;
+        xh[k][e] = x;
+        gh[k][e] = g * ga[k][e];
+        s1 += gh[k][e];
+        s2 += gh[k][e] * x;
+      }
+    s1 = sub_sum<SUB>(s1) * inv_c;
+    s2 = sub_sum<SUB>(s2) * inv_c;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
       const int cv = sub + SUB * k;
       if (rok && cv < cvec) {
         float o[V];
@@ -927,7 +949,7 @@ __global__ void layernorm_act_bwd_kernel(const T* __restrict__ z, const T* __res
   }
   // fold the row groups of the wave together, then lanes < SUB write the wave's partial row
 #pragma unroll
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < NK; ++k)
 #pragma unroll
     for (int e = 0; e < V; ++e) {
 #pragma unroll
@@ -936,50 +958,79 @@ __global__ void layernorm_act_bwd_kernel(const T* __restrict__ z, const T* __res
         pg[k][e] += __shfl_xor(pg[k][e], o);
       }
     }
+  extern __shared__ float ln_red[];  // [TPB/64 waves][2][C]
+  const int wib = threadIdx.x >> 6;
   if (rsel == 0) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NK; ++k) {
       const int cv = sub + SUB * k;
       if (cv < cvec) {
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-          part[(wave * 2 + 0) * C + cv * V + e] = pb[k][e];
-          part[(wave * 2 + 1) * C + cv * V + e] = pg[k][e];
+          ln_red[(wib * 2 + 0) * C + cv * V + e] = pb[k][e];
+          ln_red[(wib * 2 + 1) * C + cv * V + e] = pg[k][e];
         }
       }
     }
   }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 2 * C; idx += TPB) {  // one partial row per workgroup
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < TPB / 64; ++w) t += ln_red[w * 2 * C + idx];
+    part[(long)blockIdx.x * 2 * C + idx] = t;
+  }
 }
 
-// column sums of a [rows][C] tensor: part [nblk*nrl][C]; VECTOR: 16-byte loads, thread = (channel vector, row lane)
+// column sums of a [rows][C] tensor.  Thread = (channel [vector], row lane); the block's row lanes are folded through
+// LDS into ONE partial row per block: part [nblk][C]  (a narrow bias gradient, C = 8, used to leave 256 lane rows per
+// block for the finalize kernel - hundreds of microseconds for two workgroups).
 template <typename T, bool VECTOR>
 __global__ void colsum_partial_kernel(const T* __restrict__ x, long rows, int C, float* __restrict__ part,
                                       int rows_per_block, int nrl) {
   constexpr int V = 16 / sizeof(T);
+  __shared__ float red[TPB * V];  // nrl * C <= TPB * V floats whenever nrl > 1
   const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float* dst = part + (long)blockIdx.x * C;
   if (VECTOR) {
     const int cvec = C / V, rl = threadIdx.x / cvec;
-    if (rl >= nrl) return;
-    for (int cv = threadIdx.x % cvec; cv < cvec; cv += TPB) {
+    for (int cv = threadIdx.x % cvec; cv < cvec && rl < nrl; cv += TPB) {
       float acc[V];
 #pragma unroll
       for (int e = 0; e < V; ++e) acc[e] = 0.f;
-      for (long r = r0 + rl; r < r1; r += nrl) {
+      long r = r0 + rl;
+      for (; r + nrl < r1; r += 2 * nrl) {  // two rows in flight
+        float f[V], g[V];
+        ldv(x + (r * cvec + cv) * V, f);
+        ldv(x + ((r + nrl) * cvec + cv) * V, g);
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] += f[e] + g[e];
+      }
+      if (r < r1) {
         float f[V];
         ldv(x + (r * cvec + cv) * V, f);
 #pragma unroll
         for (int e = 0; e < V; ++e) acc[e] += f[e];
       }
 #pragma unroll
-      for (int e = 0; e < V; ++e) part[((long)blockIdx.x * nrl + rl) * C + cv * V + e] = acc[e];
+      for (int e = 0; e < V; ++e) {
+        if (nrl > 1) red[rl * C + cv * V + e] = acc[e]; else dst[cv * V + e] = acc[e];
+      }
     }
   } else {
     const int rl = threadIdx.x / C;
-    if (rl >= nrl) return;
-    for (int c = threadIdx.x % C; c < C; c += TPB) {
+    for (int c = threadIdx.x % C; c < C && rl < nrl; c += TPB) {
       float s = 0.f;
       for (long r = r0 + rl; r < r1; r += nrl) s += elem<T>::ld(x + r * C + c);
-      part[((long)blockIdx.x * nrl + rl) * C + c] = s;
+      if (nrl > 1) red[rl * C + c] = s; else dst[c] = s;
+    }
+  }
+  if (nrl > 1) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += TPB) {
+      float t = 0.f;
+      for (int l = 0; l < nrl; ++l) t += red[l * C + c];
+      dst[c] = t;
     }
   }
 }
@@ -1024,11 +1075,14 @@ inline int grid_fixed(long nvec, int cvec, bool* fixed) {
 #define SIHL_AFB(A, F) hipLaunchKernelGGL((affine_act_bwd_kernel<T, A, F>), dim3(g), dim3(TPB), 0, stream, (const T*)x, (const T*)dy, (T*)dx, nvec, C / V, scale, shift)
 #define SIHL_AFB_A(A) do { if (fixed) SIHL_AFB(A, true); else SIHL_AFB(A, false); } while (0)
 #define SIHL_NBR(M, A) hipLaunchKernelGGL((norm_bwd_reduce_kernel<T, M, A>), dim3(nblk), dim3(TPB), red_lds, stream, (const T*)s, (const T*)dy, rows, C, mean, rstd, gamma, beta, ws, rpb, nrl)
-#define SIHL_NBA(M, A, F) hipLaunchKernelGGL((norm_bwd_apply_kernel<T, M, A, F>), dim3(g), dim3(TPB), 0, stream, (const T*)s, (const T*)dy, (T*)dz, nvec, C / V, mean, rstd, gamma, beta, (const float*)sums, 1.f / (float)rows, batch_stats)
+#define SIHL_NBA(M, A, F) hipLaunchKernelGGL((norm_bwd_apply_kernel<T, M, A, F>), dim3(g), dim3(TPB), 0, stream, (const T*)s, (const T*)dy, (T*)dz, nvec, C / V, mean, rstd, gamma, beta, (const float*)s0, (const float*)s1, 1.f / (float)rows, batch_stats)
 #define SIHL_NBA_F(M, A) do { if (fixed) SIHL_NBA(M, A, true); else SIHL_NBA(M, A, false); } while (0)
 
-#define SIHL_LN(S, A) hipLaunchKernelGGL((layernorm_act_kernel<T, S, A>), dim3((int)g), dim3(TPB), 0, stream, (const T*)z, (T*)y, rows, C, gamma, beta, eps, mean, rstd)
-#define SIHL_LNB(S, A) hipLaunchKernelGGL((layernorm_act_bwd_kernel<T, S, A>), dim3(nwaves / 4), dim3(TPB), 0, stream, (const T*)z, (const T*)dy, (T*)dz, rows, C, gamma, beta, mean, rstd, ws)
+#define SIHL_LN(S, K, A) hipLaunchKernelGGL((layernorm_act_kernel<T, S, K, A>), dim3((int)g), dim3(TPB), 0, stream, (const T*)z, (T*)y, rows, C, gamma, beta, eps, mean, rstd)
+#define SIHL_LNB(S, K, A) hipLaunchKernelGGL((layernorm_act_bwd_kernel<T, S, K, A>), dim3(nblk), dim3(TPB), (size_t)(TPB / 64) * 2 * C * sizeof(float), stream, (const T*)z, (const T*)dy, (T*)dz, rows, C, gamma, beta, mean, rstd, ws)
+
+// lanes per row / chunks per lane by row width (cvec = 16-byte chunks per row)
+#define SIHL_LN_ALL(L, A) do { if (cvec <= 16) L(16, 1, A); else if (cvec <= 32) L(32, 1, A); else if (cvec <= 64) L(64, 1, A); else L(64, 2, A); } while (0)
 
 #define DISPATCH_DTYPE(dtype, ...)                                   \
   if (dtype == SIHL_F32) { typedef float T; __VA_ARGS__; }           \
@@ -1283,8 +1337,9 @@ int sihl_blur_fuse_bwd(const void* dout, const void* a, const void* b, const voi
 
 // Backward through BatchNorm (+ activation).  mode 0: s = act(conv) (post-activation, pre-norm), y = BN(s);
 // mode 1: s = conv (pre-norm), y = act(BN(s)).  Writes dgamma/dbeta (fp32 [C]) and dz (grad wrt conv output).
-static int reduce_blocks(long rows) {
-  long nb = (rows + 255) / 256;
+// workgroups of a column reduction: every thread folds >= 8 rows (nrl row lanes per block), at most 1024 partial rows
+static int reduce_blocks(long rows, int nrl = 1) {
+  long nb = (rows + 8L * nrl - 1) / (8L * nrl);
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
   return (int)nb;
@@ -1294,19 +1349,23 @@ static int row_lanes(int threads_per_row) { return threads_per_row >= TPB ? 1 : 
 // Workspace bytes for sihl_norm_act_bwd / sihl_colsum.
 long sihl_norm_act_bwd_ws_bytes(long rows, int C, int dtype) {
   const int cvec = C / (dtype == SIHL_BF16 ? 8 : 4);
-  return ((long)reduce_blocks(rows) * row_lanes(cvec) * 2 * C + 2L * C) * (long)sizeof(float);
+  (void)cvec;
+  return ((long)reduce_blocks(rows) * 2 * C + 2L * C) * (long)sizeof(float);  // one partial row per workgroup + sums
 }
-long sihl_colsum_ws_bytes(long rows, int C) { return (long)reduce_blocks(rows) * TPB * 8 * (long)sizeof(float) + (long)reduce_blocks(rows) * row_lanes(C) * C * (long)sizeof(float); }
+long sihl_colsum_ws_bytes(long rows, int C) { return (long)reduce_blocks(rows) * C * (long)sizeof(float); }
 
 int sihl_norm_act_bwd(const void* s, const void* dy, void* dz, long rows, int C, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, float* dgamma, float* dbeta, int mode, int act,
                       int batch_stats, int dtype, float* ws, long ws_bytes, hipStream_t stream) {
   if (!s || !dy || !dz || rows <= 0 || C <= 0 || !mean || !rstd || !ws) return SIHL_EARG;
-  const int nblk = reduce_blocks(rows);
+  const int nrl = row_lanes(C / (dtype == SIHL_BF16 ? 8 : 4));
+  const int nblk = reduce_blocks(rows, nrl);
   if (ws_bytes < sihl_norm_act_bwd_ws_bytes(rows, C, dtype)) return SIHL_EWS;
   const int rpb = (int)((rows + nblk - 1) / nblk);
-  const int nrl = row_lanes(C / (dtype == SIHL_BF16 ? 8 : 4));
-  float* sums = ws + (long)nblk * nrl * 2 * C;
+  float* sums = ws + (long)reduce_blocks(rows) * 2 * C;
+  // the column sums ARE the parameter gradients: finalize straight into the caller's buffers when given
+  float* s0 = dbeta ? dbeta : sums;
+  float* s1 = dgamma ? dgamma : sums + C;
   DISPATCH_DTYPE(dtype, {
     constexpr int V = 16 / sizeof(T);
     if (C % V) return SIHL_EARG;
@@ -1317,7 +1376,7 @@ int sihl_norm_act_bwd(const void* s, const void* dy, void* dz, long rows, int C,
     else if (act == SIHL_ACT_SIGMOID) SIHL_NBR(1, SIHL_ACT_SIGMOID);
     else SIHL_NBR(1, SIHL_ACT_NONE);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, stream, (const float*)ws,
-                       nblk, 2, C, sums);
+                       nblk, 2, C, s0, s1);
     const long nvec = rows * (C / V);
     bool fixed;
     const int g = grid_fixed(nvec, C / V, &fixed);
@@ -1334,8 +1393,6 @@ int sihl_norm_act_bwd(const void* s, const void* dy, void* dz, long rows, int C,
       }
     }
   });
-  if (dbeta) { hipError_t e = hipMemcpyAsync(dbeta, sums, C * sizeof(float), hipMemcpyDeviceToDevice, stream); if (e) return (int)e; }
-  if (dgamma) { hipError_t e = hipMemcpyAsync(dgamma, sums + C, C * sizeof(float), hipMemcpyDeviceToDevice, stream); if (e) return (int)e; }
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
 }
@@ -1350,18 +1407,18 @@ int sihl_layernorm_act(const void* z, void* y, long rows, int C, const float* ga
     if (g > 256 * 8) g = 256 * 8;
     const int cvec = C / V;
     if (act != SIHL_ACT_SILU && act != SIHL_ACT_NONE) return SIHL_EARG;
-    if (act == SIHL_ACT_SILU) { if (cvec <= 32) SIHL_LN(16, SIHL_ACT_SILU); else if (cvec <= 64) SIHL_LN(32, SIHL_ACT_SILU); else SIHL_LN(64, SIHL_ACT_SILU); }
-    else { if (cvec <= 32) SIHL_LN(16, SIHL_ACT_NONE); else if (cvec <= 64) SIHL_LN(32, SIHL_ACT_NONE); else SIHL_LN(64, SIHL_ACT_NONE); }
+    if (act == SIHL_ACT_SILU) SIHL_LN_ALL(SIHL_LN, SIHL_ACT_SILU); else SIHL_LN_ALL(SIHL_LN, SIHL_ACT_NONE);
   });
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
 }
 
+// workgroups (= partial rows) of the LayerNorm backward: 5 per CU matches the kernel's 5 waves/SIMD occupancy
 int sihl_layernorm_bwd_waves(long rows) {
   long g = (rows + 3) / 4;
-  if (g > 256 * 2) g = 256 * 2;
+  if (g > 256 * 5) g = 256 * 5;
   if (g < 1) g = 1;
-  return (int)g * 4;
+  return (int)g;
 }
 
 long sihl_layernorm_act_bwd_ws_bytes(long rows, int C) {
@@ -1373,21 +1430,18 @@ int sihl_layernorm_act_bwd(const void* z, const void* dy, void* dz, long rows, i
                            const float* beta, const float* mean, const float* rstd, int act, float* dgamma,
                            float* dbeta, int dtype, float* ws, long ws_bytes, hipStream_t stream) {
   if (!z || !dy || !dz || rows <= 0 || !gamma || !beta || !mean || !rstd || !ws) return SIHL_EARG;
-  const int nwaves = sihl_layernorm_bwd_waves(rows);
-  if (ws_bytes < (long)(nwaves * 2L * C + 2L * C) * (long)sizeof(float)) return SIHL_EWS;
-  float* sums = ws + (long)nwaves * 2 * C;
+  const int nblk = sihl_layernorm_bwd_waves(rows);
+  if (ws_bytes < (long)(nblk * 2L * C + 2L * C) * (long)sizeof(float)) return SIHL_EWS;
+  float* sums = ws + (long)nblk * 2 * C;
   DISPATCH_DTYPE(dtype, {
     constexpr int V = 16 / sizeof(T);
     if (C % V || C / V > 128) return SIHL_EARG;
     const int cvec = C / V;
     if (act != SIHL_ACT_SILU && act != SIHL_ACT_NONE) return SIHL_EARG;
-    if (act == SIHL_ACT_SILU) { if (cvec <= 32) SIHL_LNB(16, SIHL_ACT_SILU); else if (cvec <= 64) SIHL_LNB(32, SIHL_ACT_SILU); else SIHL_LNB(64, SIHL_ACT_SILU); }
-    else { if (cvec <= 32) SIHL_LNB(16, SIHL_ACT_NONE); else if (cvec <= 64) SIHL_LNB(32, SIHL_ACT_NONE); else SIHL_LNB(64, SIHL_ACT_NONE); }
+    if (act == SIHL_ACT_SILU) SIHL_LN_ALL(SIHL_LNB, SIHL_ACT_SILU); else SIHL_LN_ALL(SIHL_LNB, SIHL_ACT_NONE);
   });
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, stream, (const float*)ws, nwaves,
-                     2, C, sums);
-  if (dbeta) { hipError_t e = hipMemcpyAsync(dbeta, sums, C * sizeof(float), hipMemcpyDeviceToDevice, stream); if (e) return (int)e; }
-  if (dgamma) { hipError_t e = hipMemcpyAsync(dgamma, sums + C, C * sizeof(float), hipMemcpyDeviceToDevice, stream); if (e) return (int)e; }
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, stream, (const float*)ws, nblk,
+                     2, C, dbeta ? dbeta : sums, dgamma ? dgamma : sums + C);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
 }
@@ -1395,22 +1449,21 @@ int sihl_layernorm_act_bwd(const void* z, const void* dy, void* dz, long rows, i
 // out[c] = sum_r x[r][c]   (bias gradients).  ws: sihl_colsum_ws_bytes(rows, C)
 int sihl_colsum(const void* x, long rows, int C, float* out, int dtype, float* ws, long ws_bytes, hipStream_t stream) {
   if (!x || !out || rows <= 0 || C <= 0 || !ws) return SIHL_EARG;
-  const int nblk = reduce_blocks(rows);
   if (ws_bytes < sihl_colsum_ws_bytes(rows, C)) return SIHL_EWS;
-  const int rpb = (int)((rows + nblk - 1) / nblk);
-  int nrl = row_lanes(C);
+  int nrl = row_lanes(C), nblk = 1, rpb = 1;
   DISPATCH_DTYPE(dtype, {
     constexpr int V = 16 / sizeof(T);
+    if (C % V == 0) nrl = row_lanes(C / V);
+    nblk = reduce_blocks(rows, nrl);
+    rpb = (int)((rows + nblk - 1) / nblk);
     if (C % V == 0) {
-      nrl = row_lanes(C / V);
-      if (nrl > row_lanes(C) * V) nrl = row_lanes(C) * V;  // workspace was sized for row_lanes(C) * C floats
       hipLaunchKernelGGL((colsum_partial_kernel<T, true>), dim3(nblk), dim3(TPB), 0, stream, (const T*)x, rows, C, ws, rpb, nrl);
     } else {
       hipLaunchKernelGGL((colsum_partial_kernel<T, false>), dim3(nblk), dim3(TPB), 0, stream, (const T*)x, rows, C, ws, rpb, nrl);
     }
   });
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, stream, (const float*)ws,
-                     nblk * nrl, 1, C, out);
+                     nblk, 1, C, out, out);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
 }
