@@ -52,6 +52,7 @@ int sihl_conv2d_stat_rows(long M);
 int sihl_conv2d_force_register_staging(int on);
 /* Tuning hook: pixel-tile size of the LDS-DMA kernel for Cout > 128 (0 = heuristic, 128 or 256). */
 int sihl_conv2d_tile_override(int bm);
+int sihl_conv2d_nbuf_override(int n); /* tuning hook: LDS stages of the narrow-tile kernels, 0 = default */
 /* Tuning ablation of the LDS-DMA kernel (results are INVALID when non-zero): 1 = no in-loop DMA, 2 = no ds_read/MFMA. */
 int sihl_conv2d_debug(int mode);
 int sihl_conv2d_fwd(const void* in, const void* wt, const float* bias, void* out, int N, int H, int W, int Cin,
@@ -200,6 +201,7 @@ int sihl_ce_resize(const void* logits, const long* targets, long ignore_index, c
 int sihl_profile_enable(int on);
 int sihl_profile_collect(int slot, int dtype, long* launches, double* total_ms, double* total_flops,
                          double* total_bytes);
+long sihl_profile_records(int slot, int dtype, double* out, long cap);
 
 #ifdef __cplusplus
 }

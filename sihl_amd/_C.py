@@ -21,6 +21,7 @@ SIGNATURES = {
     "sihl_conv2d_stat_rows": (I, [L]),
     "sihl_conv2d_force_register_staging": (I, [I]),
     "sihl_conv2d_tile_override": (I, [I]),
+    "sihl_conv2d_nbuf_override": (I, [I]),
     "sihl_conv2d_debug": (I, [I]),
     "sihl_conv2d_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, P, P, P, I, P, L, L, P]),
     "sihl_conv2d_dgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
@@ -63,6 +64,7 @@ SIGNATURES = {
     "sihl_ce_resize": (I, [P, P, L, P, P, P, I, I, I, I, I, I, I, P]),
     "sihl_profile_enable": (I, [I]),
     "sihl_profile_collect": (I, [I, I, P, P, P, P]),
+    "sihl_profile_records": (L, [I, I, P, L]),
 }
 
 _lib = None

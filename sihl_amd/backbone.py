@@ -4,16 +4,16 @@ torchvision's published ResNet architecture (torchvision itself is absent here),
 level contract: level 0 is the input, level 1 = ``relu`` BEFORE max-pool, levels 2..5 = ``layer1..layer4``,
 levels above 5 come from AntialiasedDownscaler blocks.  Parameter names follow torchvision's under ``model.``.
 
-Execution: by default the trunk runs on PyTorch-ROCm (MIOpen/CK), which SURVEY §8 a2 allows ("not a hand-kernel
-target").  With ``native=True`` the residual stages (layer1..layer4 - every 1x1 / 3x3 / strided conv + BatchNorm +
-ReLU + residual merge, forward and backward) run on the sihl HIP kernels instead (conv -> BN -> ReLU is the same
-fused conv block the FPN uses; the block tail is one normalise + add + ReLU pass) - SURVEY §8(f) rank 2, parity-
-tested against the oracle ResNet in tests/test_gpu_backbone.py.  Measured on the flagship step: 535 img/s native vs
-557 img/s MIOpen (round 1), so the default stays MIOpen; native removes MIOpen's ~45 s first-iteration JIT.  The 7x7
-stem (3 input channels) + max-pool stay on PyTorch-ROCm in both modes.  On CPU tensors (BASELINE config 1, "stock
-PyTorch plumbing") the same parameters run through plain torch ops.
+Execution: on a HIP device the residual stages (layer1..layer4 - every 1x1 / 3x3 / strided conv + BatchNorm + ReLU +
+residual merge, forward and backward) run on the sihl HIP kernels (``native=None`` or ``True``): conv -> BN -> ReLU is
+the same fused conv block the FPN uses, and the block tail is one normalise + add + ReLU pass - SURVEY §8(f) rank 2,
+parity-tested against the oracle ResNet in tests/test_gpu_backbone.py.  ``native=False`` runs the trunk on
+PyTorch-ROCm (MIOpen/CK), which SURVEY §8 a2 allows ("not a hand-kernel target").  Measured on the flagship step
+(round 1, bs 32, 512^2, bf16): 689 img/s native vs 666 img/s MIOpen, and native has no ~45 s MIOpen JIT in the first
+iteration.  The 7x7 stem (3 input channels) + max-pool stay on PyTorch-ROCm in both modes.  CPU tensors (BASELINE
+config 1, "stock PyTorch plumbing") always run through plain torch ops with the same parameters.
 """
-from typing import List
+from typing import List, Optional
 
 import torch
 import torch.nn.functional as F
@@ -134,9 +134,9 @@ class _Trunk(nn.Module):
 
 class ResNetBackbone(nn.Module):
     def __init__(self, name: str = "resnet50", pretrained: bool = False, input_channels: int = 3,
-                 top_level: int = 5, frozen_levels: int = 0, native: bool = False):
-        """native: False (default) = PyTorch ops (MIOpen on ROCm); True = residual stages on the sihl HIP kernels
-        (HIP device required)."""
+                 top_level: int = 5, frozen_levels: int = 0, native: Optional[bool] = None):
+        """native: None (default) = sihl HIP kernels for the residual stages whenever the input is on a HIP device;
+        True = require them (error on CPU input); False = PyTorch ops (MIOpen on ROCm)."""
         super().__init__()
         self.native = native
         if name not in RESNETS:
@@ -172,7 +172,7 @@ class ResNetBackbone(nn.Module):
         assert input.shape[3] % 2 ** self.top_level == 0
         H, W = input.shape[2:]
         outs = [input]
-        native = bool(self.native)
+        native = input.is_cuda if self.native is None else bool(self.native)
         if native and not input.is_cuda:
             raise RuntimeError("native=True needs a HIP device (no CPU fallback for the HIP residual stages)")
         if native and input.dim() == 4 and not input.is_contiguous(memory_format=torch.channels_last):

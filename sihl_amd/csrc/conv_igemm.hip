@@ -45,6 +45,7 @@ struct ConvParams {
 bool g_force_reg = false;  // test hook: use the register-staged loader
 int g_dbg = 0;
 int g_tile_override = 0;    // test / tuning hook: 0 = heuristic, 128 / 256 = force that pixel-tile size
+int g_nbuf = 0;             // tuning hook: LDS stages of the narrow LDS-DMA tiles (0 = default)
 
 constexpr int BM128 = 128;
 constexpr int KCB = 128;         // bytes of K per stage per row
@@ -306,7 +307,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 // given an out-of-range buffer offset: the hardware bounds check returns zeros, which land in LDS.
 
 // DIL: strided-dgrad instantiation (input read as if zero-dilated); the common case compiles without it.
-template <typename T, int BM, int BN, int WM, int WN, bool DIL>
+// NBUF LDS stages: NBUF - 1 stages of DMA are in flight while one is multiplied.  Two suffice for the 256x256 tile
+// (a stage of MFMAs outlasts a DMA round trip); the narrow tiles of small / thin layers were bound by one DMA
+// latency per 64-deep stage and take 3-4.
+template <int N> __device__ __forceinline__ void wait_vm_keep() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int BM, int BN, int WM, int WN, bool DIL, int NBUF>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(const ConvParams p) {
   constexpr int NTHREADS = WM * WN * 64;
   constexpr int VEC = 16 / (int)sizeof(T);
@@ -315,7 +321,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(const Conv
   constexpr int A_BYTES = BM * KCB, B_BYTES = BN * KCB, STAGE = A_BYTES + B_BYTES;
   constexpr int NA = BM * 8 / NTHREADS, NBL = BN * 8 / NTHREADS;  // 16-byte slots per thread per stage
   constexpr int NKS = KCB / 32;                                    // k-steps per stage
+  constexpr int PER_STAGE = NA + NBL;                              // DMA instructions per thread per stage
   static_assert(NA >= 1 && NBL >= 1, "tile too small for the thread count");
+  static_assert(NBUF >= 2 && NBUF <= 4 && (NBUF - 2) * PER_STAGE <= 63, "vmcnt immediate range");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -348,7 +356,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(const Conv
     a_off[j] = 0;
     a_mask[j] = 0;
     a_iy0[j] = a_ix0[j] = 0;
-    if (m < p.M) {
+    if (m < p.M && !DIL && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0) {
+      // pointwise conv: output pixel m reads input pixel m, no borders (skips two divisions + the tap loop per slot)
+      a_mask[j] = 1u;
+      a_off[j] = (unsigned)(((long)m * p.Cin + a_ch[j]) * (long)sizeof(T));
+    } else if (m < p.M) {
       const int hw = p.Ho * p.Wo;
       const int n = m / hw, r = m - n * hw;
       const int oy = r / p.Wo, ox = r - oy * p.Wo;
@@ -386,11 +398,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(const Conv
   // scalar state of the stage being prefetched
   int n_kc = 0, n_tap = 0, n_adelta = 0, n_bdelta = 0, n_ky = 0, n_kx = 0;
   unsigned n_abase = 0, n_bbase = 0, n_tapbit = 1;
-  auto stage_setup = [&](int s, int buf) {
-    n_kc = s / ntaps;
-    n_tap = s - n_kc * ntaps;
-    n_ky = n_tap / p.KW;
-    n_kx = n_tap - n_ky * p.KW;
+  // stages are visited in order (tap fastest, then channel chunk): counters advance by one instead of dividing
+  // (two runtime integer divisions per stage were ~0.25 us of dependent VALU latency in a loop whose useful work
+  // on a narrow tile is ~0.5 us)
+  int c_kc = 0, c_tap = -1, c_ky = 0, c_kx = -1;
+  auto stage_setup = [&](int /*s*/, int buf) {
+    if (++c_tap == ntaps) { c_tap = 0; c_ky = 0; c_kx = 0; ++c_kc; }
+    else if (++c_kx == p.KW) { c_kx = 0; ++c_ky; }
+    n_kc = c_kc; n_tap = c_tap; n_ky = c_ky; n_kx = c_kx;
     n_tapbit = 1u << n_tap;
     n_adelta = ((n_ky * p.dil * p.W + n_kx * p.dil) * p.Cin) * (int)sizeof(T) + n_kc * KCB;
     n_bdelta = n_tap * p.Cin * (int)sizeof(T) + n_kc * KCB;
@@ -428,24 +443,36 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(const Conv
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) koff[ks] = fr * KCB + (((ks * 2 + fh) ^ fsw) << 4);
 
-  stage_setup(0, 0);
+  // wait until at most `keep` of the newest stage groups are still in flight (vm ops retire in order)
+  auto wait_keep = [&](int keep) {
+    if (NBUF >= 4 && keep >= 2) wait_vm_keep<2 * PER_STAGE>();
+    else if (NBUF >= 3 && keep >= 1) wait_vm_keep<PER_STAGE>();
+    else wait_vm_keep<0>();
+  };
 #pragma unroll
-  for (int j = 0; j < NA; ++j) issue_a(j);
+  for (int s0 = 0; s0 < NBUF - 1; ++s0) {
+    if (s0 < nstages) {
+      stage_setup(s0, s0);
 #pragma unroll
-  for (int j = 0; j < NBL; ++j) issue_b(j);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int j = 0; j < NA; ++j) issue_a(j);
+#pragma unroll
+      for (int j = 0; j < NBL; ++j) issue_b(j);
+    }
+  }
+  wait_keep(min(NBUF - 2, nstages - 1));
   __syncthreads();
 
-  for (int s = 0; s < nstages; ++s) {
-    const bool more = (s + 1 < nstages) && !(p.dbg & 1);
-    if (more) stage_setup(s + 1, (s + 1) & 1);
-    const char* As = smem + (s & 1) * STAGE + wm * WTM * KCB;
-    const char* Bs = smem + (s & 1) * STAGE + A_BYTES + wn * WTN * KCB;
+  int buf = 0, nbuf_next = NBUF - 1;  // LDS stage being multiplied / being filled
+  for (int s = 0; s < ((p.dbg & 64) ? 0 : nstages); ++s) {  // dbg 64: tuning ablation, prologue + epilogue only
+    const bool more = (s + NBUF - 1 < nstages) && !(p.dbg & 1);
+    if (more) stage_setup(s + NBUF - 1, nbuf_next);
+    const char* As = smem + buf * STAGE + wm * WTM * KCB;
+    const char* Bs = smem + buf * STAGE + A_BYTES + wn * WTN * KCB;
     // DMA issue schedule for the next stage (p.dbg bits 2-3 select it while tuning):
     //   0: NA/NBL slots spread over the k-steps   1: everything before the first k-step
     //   2: staggered - waves of the first half issue before k-step 0, the others after k-step 1
     //   3: front-loaded - slots spread over the first half of the k-steps
-    const int sched = (p.dbg & 16) ? ((p.dbg >> 2) & 3) : (BM >= 256 ? 3 : 1);
+    const int sched = (p.dbg & 16) ? ((p.dbg >> 2) & 3) : ((BM >= 256 && NBUF == 2) ? 3 : 1);
     const bool early = sched == 1 || (sched == 2 && wave < WM * WN / 2);
     if (!(p.dbg & 2)) {
       uint4 fa[2][MT], fb[2][NT];
@@ -498,30 +525,33 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(const Conv
 #pragma unroll
       for (int j = 0; j < NBL; ++j) issue_b(j);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed ...
-    __syncthreads();                                   // ... and so have everybody else's
+    // stage s+1 must have landed: only the stages issued after it may still be in flight ...
+    wait_keep(max(0, min(NBUF - 2, nstages - 2 - s)));
+    __syncthreads();  // ... for every wave, and everyone is done reading stage s
+    buf = buf + 1 == NBUF ? 0 : buf + 1;
+    nbuf_next = nbuf_next + 1 == NBUF ? 0 : nbuf_next + 1;
   }
   if (p.dbg & 32) return;  // tuning ablation: no epilogue
   conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, tile_m, m0, n0);
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int NBUF = 2>
 int launch_dma(const ConvParams& p0, hipStream_t stream) {
   ConvParams p = p0;
   p.gridM = (p.M + BM - 1) / BM;
   p.gridN = (p.Cout + BN - 1) / BN;
   constexpr int EPI = BM * (BN * (int)sizeof(T) + 16) + 2 * WM * BN * 4;
-  constexpr int STAGES2 = 2 * (BM + BN) * KCB;
+  constexpr int STAGES2 = NBUF * (BM + BN) * KCB;
   constexpr int LDS = STAGES2 > EPI ? STAGES2 : EPI;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
-  auto kern = p.in_dilate > 1 ? conv_igemm_dma_kernel<T, BM, BN, WM, WN, true>
-                              : conv_igemm_dma_kernel<T, BM, BN, WM, WN, false>;
+  auto kern = p.in_dilate > 1 ? conv_igemm_dma_kernel<T, BM, BN, WM, WN, true, NBUF>
+                              : conv_igemm_dma_kernel<T, BM, BN, WM, WN, false, NBUF>;
   if (!attr_set) {
-    hipError_t e0 = hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<T, BM, BN, WM, WN, true>,
+    hipError_t e0 = hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<T, BM, BN, WM, WN, true, NBUF>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e0 != hipSuccess) return (int)e0;
-    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<T, BM, BN, WM, WN, false>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<T, BM, BN, WM, WN, false, NBUF>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
@@ -560,6 +590,29 @@ int launch_reg(const ConvParams& p0, hipStream_t stream) {
   return SIHL_OK;
 }
 
+// stage-count selection of the narrow tiles (g_nbuf: tuning hook, 0 = default)
+// Two stages keep the LDS footprint at <= 64 KB, so two workgroups share a CU and hide each other's waits - worth
+// more than a deeper pipeline whenever the grid has more workgroups than CUs (measured: L4 3x3 60 us with 2 stages,
+// 93 us with 4).  Grids of <= 256 workgroups are alone on their CU anyway and take 4 stages (lat5 1x1 K=2048:
+// 42 -> 32 us).
+template <typename T, int BN> int stages_for(const ConvParams& p) {
+  if (g_nbuf) return g_nbuf;
+  const long wgs = ((p.M + 127) / 128) * ((p.Cout + BN - 1) / BN);
+  return wgs <= 256 ? 4 : 2;
+}
+template <typename T> int launch_n64(const ConvParams& p, hipStream_t stream) {
+  const int nb = stages_for<T, 64>(p);
+  if (nb == 2) return launch_dma<T, 128, 64, 4, 1, 2>(p, stream);
+  if (nb == 3) return launch_dma<T, 128, 64, 4, 1, 3>(p, stream);
+  return launch_dma<T, 128, 64, 4, 1, 4>(p, stream);
+}
+template <typename T> int launch_n128(const ConvParams& p, hipStream_t stream) {
+  const int nb = stages_for<T, 128>(p);
+  if (nb == 2) return launch_dma<T, 128, 128, 2, 2, 2>(p, stream);
+  if (nb == 3) return launch_dma<T, 128, 128, 2, 2, 3>(p, stream);
+  return launch_dma<T, 128, 128, 2, 2, 4>(p, stream);
+}
+
 template <typename T>
 int dispatch(const ConvParams& p, hipStream_t stream) {
   constexpr int VEC = 16 / (int)sizeof(T);
@@ -582,13 +635,18 @@ int dispatch(const ConvParams& p, hipStream_t stream) {
         return launch_dma<T, 256, 256, 4, 2>(p, stream);
     }
     if (g_tile_override == 64 || (g_tile_override == 0 && tiles128 * ((p.Cout + 255) / 256) <= 64))
-      return launch_dma<T, 128, 64, 4, 1>(p, stream);
+      return launch_n64<T>(p, stream);
     if (g_tile_override == 1280 || (g_tile_override == 0 && tiles128 * ((p.Cout + 255) / 256) <= 256))
-      return launch_dma<T, 128, 128, 2, 2>(p, stream);
-    return launch_dma<T, 128, 256, 2, 2>(p, stream);
+      return launch_n128<T>(p, stream);
+    // bf16 below 65536 pixels: 128x128 tiles beat 128x256 (r3 1x1 256>1024: 53 vs 68 us; r4 1x1 512>2048: 39 vs 49)
+    if constexpr (sizeof(T) == 2) {
+      if (g_tile_override == 0) return launch_n128<T>(p, stream);
+    }
+    if (g_nbuf == 3) return launch_dma<T, 128, 256, 2, 2, 3>(p, stream);
+    return launch_dma<T, 128, 256, 2, 2, 2>(p, stream);
   }
-  if (p.Cout > 64) return launch_dma<T, 128, 128, 2, 2>(p, stream);
-  return launch_dma<T, 128, 64, 4, 1>(p, stream);
+  if (p.Cout > 64) return launch_n128<T>(p, stream);
+  return launch_n64<T>(p, stream);
 }
 
 }  // namespace
@@ -600,6 +658,9 @@ int sihl_conv2d_force_register_staging(int on) { g_force_reg = on != 0; return 0
 
 // Tuning ablation (results invalid when non-zero): 1 = skip the in-loop DMA, 2 = skip ds_read/MFMA.
 int sihl_conv2d_debug(int mode) { g_dbg = mode; return 0; }
+
+// Tuning hook: LDS stages of the narrow-tile LDS-DMA kernels (0 = default, 2..4).
+int sihl_conv2d_nbuf_override(int n) { g_nbuf = n; return 0; }
 
 // Tuning hook: force the pixel-tile size of the LDS-DMA kernel (0 = heuristic, 128, 256).
 int sihl_conv2d_tile_override(int bm) { g_tile_override = bm; return 0; }

@@ -67,18 +67,45 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int R, int C,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* running_mean, float* running_var, float* mean_out,
                                    float* rstd_out, float* scale, float* shift) {
-  // 256 threads = 4 channels x 64 row lanes (layers with few channels still spread over C/4 workgroups)
+  // One workgroup per 4 channels (layers with few channels still spread over C/4 workgroups).  When C % 4 == 0 every
+  // thread owns whole partial rows and reads the 4 sums and 4 squared sums of a row as two 16-byte loads (the
+  // stage-1 layers have 4096 partial rows: 64 scalar loads per thread took ~15 us); the 256 threads are then folded
+  // in double through wave shuffles and LDS.
   __shared__ double sh[2][64][5];
   const int cx = threadIdx.x & 3, ry = threadIdx.x >> 2;
   const int c = blockIdx.x * 4 + cx;
   double s = 0.0, q = 0.0;
-  if (c < C)
-    for (int r = ry; r < R; r += 64) {
-      s += (double)part[((long)r * 2 + 0) * C + c];
-      q += (double)part[((long)r * 2 + 1) * C + c];
+  if ((C & 3) == 0) {
+    double ds[4] = {0.0, 0.0, 0.0, 0.0}, dq[4] = {0.0, 0.0, 0.0, 0.0};
+    const int c0 = blockIdx.x * 4;
+    for (int r = threadIdx.x; r < R; r += 256) {
+      const float4 a = *(const float4*)(part + ((long)r * 2 + 0) * C + c0);
+      const float4 b4 = *(const float4*)(part + ((long)r * 2 + 1) * C + c0);
+      ds[0] += (double)a.x; ds[1] += (double)a.y; ds[2] += (double)a.z; ds[3] += (double)a.w;
+      dq[0] += (double)b4.x; dq[1] += (double)b4.y; dq[2] += (double)b4.z; dq[3] += (double)b4.w;
     }
-  sh[0][ry][cx] = s;
-  sh[1][ry][cx] = q;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { ds[k] += __shfl_xor(ds[k], o); dq[k] += __shfl_xor(dq[k], o); }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // park the 4 wave totals in rows 0..3 of the table the common tail sums over (rows 4..63 stay zero)
+    for (int i = threadIdx.x; i < 2 * 64 * 5; i += 256) (&sh[0][0][0])[i] = 0.0;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { sh[0][wave][k] = ds[k]; sh[1][wave][k] = dq[k]; }
+    }
+  } else {
+    if (c < C)
+      for (int r = ry; r < R; r += 64) {
+        s += (double)part[((long)r * 2 + 0) * C + c];
+        q += (double)part[((long)r * 2 + 1) * C + c];
+      }
+    sh[0][ry][cx] = s;
+    sh[1][ry][cx] = q;
+  }
   __syncthreads();
   if (ry == 0 && c < C) {
     s = q = 0.0;

@@ -63,4 +63,22 @@ int sihl_profile_collect(int slot, int dtype, long* launches, double* total_ms, 
   return 0;
 }
 
+// Per-launch records of (slot, dtype) in launch order: out[3*i + {0,1,2}] = milliseconds, flops, bytes.
+// Returns the number of records (which may exceed cap; only cap are written), negative on error.
+long sihl_profile_records(int slot, int dtype, double* out, long cap) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  long n = 0;
+  for (auto& r : g_recs) {
+    if (r.slot != slot || r.dtype != dtype) continue;
+    if (out && n < cap) {
+      if (hipEventSynchronize(r.b) != hipSuccess) return -1;
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return -1;
+      out[3 * n] = t; out[3 * n + 1] = r.flops; out[3 * n + 2] = r.bytes;
+    }
+    ++n;
+  }
+  return n;
+}
+
 }  // extern "C"

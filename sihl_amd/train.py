@@ -39,6 +39,8 @@ def configure_optimizer(model: nn.Module, optimizer=torch.optim.AdamW, lr: float
     if optimizer in (torch.optim.AdamW, torch.optim.Adam) and "fused" not in kw and "foreach" not in kw:
         # one multi-tensor kernel per group instead of a host loop over ~400 parameters
         kw["fused"] = all(p.is_cuda for g in param_groups for p in g["params"])
+    if kw.get("capturable") and not all(p.is_cuda for g in param_groups for p in g["params"]):
+        kw.pop("capturable")
     return optimizer(param_groups, lr=lr, weight_decay=weight_decay, **kw)
 
 
@@ -127,19 +129,59 @@ def broadcast_parameters(model: nn.Module, src: int = 0, group=None) -> None:
         dist.broadcast(t.data, src=src, group=group)
 
 
+def _tree_tensors(obj, out: List[Tensor]) -> List[Tensor]:
+    """All tensors of a nest of dicts / lists / tuples, in a fixed traversal order."""
+    if isinstance(obj, Tensor):
+        out.append(obj)
+    elif isinstance(obj, dict):
+        for k in sorted(obj):
+            _tree_tensors(obj[k], out)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _tree_tensors(v, out)
+    return out
+
+
+def _tree_clone(obj):
+    if isinstance(obj, Tensor):
+        return obj.clone()
+    if isinstance(obj, dict):
+        return {k: _tree_clone(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_tree_clone(v) for v in obj)
+    return obj
+
+
 class Trainer:
     """One optimisation step = forward (backbone -> neck -> heads' training_step) + backward +
-    gradient all-reduce + clip + optimizer step."""
+    gradient all-reduce + clip + optimizer step.
+
+    ``graph=True`` (single-process runs on a HIP device): after ``GRAPH_WARMUP`` eager steps the whole step -
+    forward, losses, backward, clipping, AdamW - is captured into ONE HIP graph per input signature (tensor shapes
+    of the images and of every target) and later steps copy their batch into the graph's static buffers and replay
+    it: ~2 000 kernel launches per step without host work in between.  The step contains no host synchronisation
+    (see ObjectDetection.training_step), which is what makes it capturable.  Batches with a new signature run
+    eagerly until their own graph exists.  Multi-process runs stay eager: their bucketed all-reduces are issued
+    from autograd hooks and overlap backward."""
+
+    GRAPH_WARMUP = 2
 
     def __init__(self, model: nn.Module, optimizer: Optional[torch.optim.Optimizer] = None, group=None,
                  grad_clip_norm: Optional[float] = 0.1, autocast_dtype: Optional[torch.dtype] = None,
-                 bucket_mb: float = 32.0, **opt_kw):
+                 bucket_mb: float = 32.0, graph: bool = False, **opt_kw):
         self.model = model
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        on_gpu = all(p.is_cuda for p in model.parameters())
+        self.use_graph = bool(graph) and world == 1 and on_gpu
+        if self.use_graph and optimizer is None:
+            opt_kw.setdefault("capturable", True)  # optimizer step counters live on the device
         self.optimizer = optimizer or configure_optimizer(model, **opt_kw)
         self.grad_clip_norm = grad_clip_norm
         self.autocast_dtype = autocast_dtype
         broadcast_parameters(model, group=group)
         self.averager = GradientAverager(list(model.parameters()), group=group, bucket_mb=bucket_mb)
+        self._graphs: Dict[Any, Any] = {}
+        self._seen: Dict[Any, int] = {}
 
     def forward_loss(self, images: Tensor, targets: List[Any]):
         dev_type = images.device.type
@@ -158,8 +200,7 @@ class Trainer:
             metrics.update({f"head{i}/train/{k}": v for k, v in m.items()})
         return torch.stack(losses).sum(), metrics
 
-    def step(self, images: Tensor, targets: List[Any]):
-        self.model.train()
+    def _eager_step(self, images: Tensor, targets: List[Any]):
         self.optimizer.zero_grad(set_to_none=True)
         loss, metrics = self.forward_loss(images, targets)
         loss.backward()
@@ -169,3 +210,35 @@ class Trainer:
                                            self.grad_clip_norm)
         self.optimizer.step()
         return loss.detach(), metrics
+
+    def _capture(self, images: Tensor, targets: List[Any]):
+        static_images, static_targets = images.clone(), _tree_clone(targets)
+        self.optimizer.zero_grad(set_to_none=True)  # gradients are (re)created inside the graph's memory pool
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss, metrics = self.forward_loss(static_images, static_targets)
+            loss.backward()
+            if self.grad_clip_norm is not None:
+                torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.grad is not None],
+                                               self.grad_clip_norm)
+            self.optimizer.step()
+        leaves = [static_images] + _tree_tensors(static_targets, [])
+        return graph, leaves, loss.detach(), {k: (v.detach() if isinstance(v, Tensor) else v) for k, v in metrics.items()}
+
+    def step(self, images: Tensor, targets: List[Any]):
+        self.model.train()
+        if not self.use_graph:
+            return self._eager_step(images, targets)
+        leaves = [images] + _tree_tensors(targets, [])
+        sig = tuple((tuple(t.shape), t.dtype) for t in leaves)
+        entry = self._graphs.get(sig)
+        if entry is None:
+            seen = self._seen.get(sig, 0)
+            self._seen[sig] = seen + 1
+            if seen < self.GRAPH_WARMUP:
+                return self._eager_step(images, targets)
+            entry = self._graphs[sig] = self._capture(images, targets)  # capturing does not execute the step ...
+        graph, static_leaves, loss, metrics = entry
+        torch._foreach_copy_(static_leaves, leaves)
+        graph.replay()  # ... the replay does
+        return loss, metrics

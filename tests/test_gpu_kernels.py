@@ -42,6 +42,9 @@ CONV_SHAPES = [
     (2, 8, 8, 1024, 2048, 1, 2, 0),
     (2, 32, 32, 64, 256, 1, 1, 0),   # ResNet layer1 shapes
     (2, 32, 32, 64, 64, 3, 1, 1),
+    (2, 16, 16, 128, 128, 3, 1, 1),  # ResNet layer2 3x3: 2x2 tiles of the all-taps wgrad
+    (2, 16, 16, 128, 128, 3, 2, 1),
+    (2, 9, 11, 72, 120, 3, 1, 1),    # ragged 64-channel tiles in the all-taps wgrad
 ]
 
 
