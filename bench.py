@@ -161,10 +161,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(n_warm):
+    trace = (lambda m: print(f"[bench] {m}", file=sys.stderr, flush=True)) if os.environ.get("SIHL_BENCH_TRACE") \
+        else (lambda m: None)
+
+    for i in range(n_warm):
         trainer.step(images, targets)
+        trace(f"warm-up step {i} issued")
     lib = _C.lib()
     sync()
+    trace("warm-up done")
     if not use_graph:
         lib.sihl_profile_enable(1)
     t0 = time.perf_counter()
@@ -172,6 +177,7 @@ def main():
         loss, _ = trainer.step(images, targets)
     sync()
     dt = time.perf_counter() - t0
+    trace("timed steps done")
     lib.sihl_profile_enable(0)
     final_loss = float(loss)
     profiled_steps = args.steps
@@ -181,6 +187,7 @@ def main():
         for _ in range(profiled_steps):
             trainer._eager_step(images, targets)
         torch.cuda.synchronize()
+        trace("profiled eager steps done")
         lib.sihl_profile_enable(0)
 
     t = torch.tensor([dt], device=device, dtype=torch.float64)

@@ -209,7 +209,9 @@ class Trainer:
             torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.grad is not None],
                                            self.grad_clip_norm)
         self.optimizer.step()
-        return loss.detach(), metrics
+        # detached: a caller holding on to graph-attached metrics would keep this step's autograd graph - and its
+        # AccumulateGrad nodes, which remember the stream they were created on - alive into a later graph capture
+        return loss.detach(), {k: (v.detach() if isinstance(v, Tensor) else v) for k, v in metrics.items()}
 
     def _capture(self, images: Tensor, targets: List[Any]):
         static_images, static_targets = images.clone(), _tree_clone(targets)

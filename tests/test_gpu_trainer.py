@@ -1,0 +1,70 @@
+"""GPU: the HIP-graph training step (Trainer(graph=True)) against the same steps launched eagerly."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model():
+    import sihl_amd
+    torch.manual_seed(0)
+    backbone = sihl_amd.ResNetBackbone("resnet18", top_level=5)
+    neck = sihl_amd.layers.BiFPN(backbone.out_channels, 32, 3, 6, num_layers=1)
+    head = sihl_amd.heads.ObjectDetection(neck.out_channels, num_classes=5, bottom_level=3, top_level=6, num_channels=32)
+    return sihl_amd.SihlModel(backbone, neck, [head]).cuda().to(memory_format=torch.channels_last)
+
+
+def _batch(seed, n_boxes):
+    g = torch.Generator().manual_seed(seed)
+    images = torch.rand(len(n_boxes), 3, 128, 128, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    boxes, classes = [], []
+    for n in n_boxes:
+        xy = torch.rand(n, 2, generator=g) * 70
+        wh = 20 + torch.rand(n, 2, generator=g) * 30
+        boxes.append(torch.cat([xy, xy + wh], 1).cuda())
+        classes.append(torch.randint(0, 5, (n,), generator=g).cuda())
+    return images, [{"classes": classes, "boxes": boxes}]
+
+
+# Training is chaotic: a last-bit difference (atomic accumulation order in index_add's backward) is amplified by Adam's
+# normalisation into a different lr-sized step for noise-dominated elements.  A small lr keeps the two trajectories
+# comparable over the handful of steps this test runs.
+LR = 1e-5
+
+
+@pytest.mark.parametrize("amp", [None, torch.bfloat16])
+def test_graph_step_matches_eager(amp):
+    from sihl_amd.train import Trainer
+    ref_model = _model()
+    graph_model = copy.deepcopy(ref_model)
+    eager = Trainer(ref_model, lr=LR, grad_clip_norm=0.1, autocast_dtype=amp)
+    graphed = Trainer(graph_model, lr=LR, grad_clip_norm=0.1, autocast_dtype=amp, graph=True)
+    assert graphed.use_graph
+    # same signature (3 images with 2, 0, 3 boxes) for every step, different contents per step
+    for step in range(Trainer.GRAPH_WARMUP + 4):
+        images, targets = _batch(step, (2, 0, 3))
+        le, _ = eager.step(images, targets)
+        lg, _ = graphed.step(images, targets)
+        tol = 1e-4 if amp is None else 3e-2
+        torch.testing.assert_close(lg.float(), le.float(), rtol=tol, atol=tol, msg=lambda s: f"step {step}: {s}")
+    assert len(graphed._graphs) == 1  # the later steps replayed one captured graph
+    # every element within a few lr-sized steps, and the tensors equal on average to far below one step
+    max_tol, mean_tol = (3 * LR, 0.1 * LR) if amp is None else (2e-3, 2e-4)
+    for (n, a), b in zip(ref_model.named_parameters(), graph_model.parameters()):
+        d = (a.float() - b.float()).abs()
+        assert float(d.max()) <= max_tol, (n, float(d.max()))
+        assert float(d.mean()) <= mean_tol, (n, float(d.mean()))
+    tol = 1e-3 if amp is None else 2e-2
+    for (n, a), b in zip(ref_model.named_buffers(), graph_model.buffers()):
+        torch.testing.assert_close(b.float(), a.float(), rtol=tol, atol=tol, msg=lambda s: f"{n}: {s}")
+
+
+def test_graph_trainer_new_signature_runs_eagerly_then_captures():
+    from sihl_amd.train import Trainer
+    tr = Trainer(_model(), lr=1e-3, graph=True)
+    for n_boxes in ((1, 2), (1, 2), (1, 2), (3, 0), (1, 2)):
+        loss, _ = tr.step(*_batch(0, n_boxes))
+        assert torch.isfinite(loss)
+    assert len(tr._graphs) == 1 and tr._seen[next(iter(tr._graphs))] >= Trainer.GRAPH_WARMUP
