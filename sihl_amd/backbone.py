@@ -27,7 +27,7 @@ def _conv_bn(x: Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, act, training: bool
     """conv -> BatchNorm -> act on NHWC tensors through the fused HIP conv block (torchvision order); with
     ``residual`` the block tail relu(BN(conv(x)) + residual) is one normalise+add+ReLU pass."""
     if training:
-        bn.num_batches_tracked += 1
+        ops.bump_counter(bn.num_batches_tracked)
     return ops.conv_block(x, conv.weight, None, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                           stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0], act=act,
                           order="norm_act", training=training, eps=bn.eps, momentum=bn.momentum, residual=residual)

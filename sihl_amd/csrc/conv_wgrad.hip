@@ -465,13 +465,43 @@ __global__ __launch_bounds__(256) void conv_wgrad_alltaps_kernel(const WgradPara
     }
 }
 
+// dw[i] (+)= sum_k ws[k][i]: every thread owns 4 consecutive weights (16-byte loads) and keeps four split slabs in
+// flight; the scalar version (one float per thread, one slab at a time) ran at ~1.6 TB/s over up to 64 MB of slabs.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n, int splits,
                                     int accumulate) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += ws[(long)k * n + i];
-  dw[i] = accumulate ? dw[i] + s : s;
+  if (i + 4 <= n && (n & 3) == 0) {
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    int k = 0;
+    for (; k + 4 <= splits; k += 4) {
+      const float4 v0 = *(const float4*)(ws + (long)k * n + i);
+      const float4 v1 = *(const float4*)(ws + (long)(k + 1) * n + i);
+      const float4 v2 = *(const float4*)(ws + (long)(k + 2) * n + i);
+      const float4 v3 = *(const float4*)(ws + (long)(k + 3) * n + i);
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+      a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+      a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+    }
+    for (; k < splits; ++k) {
+      const float4 v0 = *(const float4*)(ws + (long)k * n + i);
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    }
+    float4 r = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                           (a0.w + a1.w) + (a2.w + a3.w));
+    if (accumulate) {
+      const float4 o = *(const float4*)(dw + i);
+      r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+    }
+    *(float4*)(dw + i) = r;
+  } else {
+    for (long j = i; j < n && j < i + 4; ++j) {
+      float t = 0.f;
+      for (int k = 0; k < splits; ++k) t += ws[(long)k * n + j];
+      dw[j] = accumulate ? dw[j] + t : t;
+    }
+  }
 }
 
 bool g_wgrad_force_reg = false;
@@ -634,7 +664,7 @@ int sihl_conv2d_wgrad(const void* in, const void* dout, float* dw, int N, int H,
   else if (dtype == SIHL_BF16) rc = launch<bf16_t>(p, stream);
   else return SIHL_EARG;
   if (rc) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream,
                      (const float*)ws, dw, n, p.splits, accumulate);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;

@@ -75,6 +75,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int R, int C,
   const int cx = threadIdx.x & 3, ry = threadIdx.x >> 2;
   const int c = blockIdx.x * 4 + cx;
   double s = 0.0, q = 0.0;
+  int nrows = 64;  // rows of `sh` that hold partial sums
   if ((C & 3) == 0) {
     double ds[4] = {0.0, 0.0, 0.0, 0.0}, dq[4] = {0.0, 0.0, 0.0, 0.0};
     const int c0 = blockIdx.x * 4;
@@ -90,13 +91,12 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int R, int C,
       for (int o = 32; o > 0; o >>= 1) { ds[k] += __shfl_xor(ds[k], o); dq[k] += __shfl_xor(dq[k], o); }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // park the 4 wave totals in rows 0..3 of the table the common tail sums over (rows 4..63 stay zero)
-    for (int i = threadIdx.x; i < 2 * 64 * 5; i += 256) (&sh[0][0][0])[i] = 0.0;
-    __syncthreads();
+    // park the 4 wave totals in rows 0..3 of the table the common tail sums over
     if (lane == 0) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) { sh[0][wave][k] = ds[k]; sh[1][wave][k] = dq[k]; }
     }
+    nrows = 4;
   } else {
     if (c < C)
       for (int r = ry; r < R; r += 64) {
@@ -109,7 +109,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int R, int C,
   __syncthreads();
   if (ry == 0 && c < C) {
     s = q = 0.0;
-    for (int k = 0; k < 64; ++k) { s += sh[0][k][cx]; q += sh[1][k][cx]; }
+    for (int k = 0; k < nrows; ++k) { s += sh[0][k][cx]; q += sh[1][k][cx]; }
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -1095,6 +1095,64 @@ inline int grid_fixed(long nvec, int cvec, bool* fixed) {
   return g;
 }
 
+// ------------------------------------------------------------------ per-step operand copies of ALL weights
+// One launch turns every fp32 master weight (logical [O][I][KH][KW], any strides) into the two bf16 operands the
+// conv kernels read: w [Op][KH][KW][I] (forward / wgrad layout, rows O..Op-1 zero) and wt [I][KH][KW][Op] (spatially
+// flipped when flip != 0: the dgrad operand).  Replaces one cast kernel + one flip/transpose kernel per layer per
+// step (~240 launches).  A workgroup covers 2048 consecutive destination elements of one weight.
+struct WeightDesc {
+  const float* src; bf16_t* w; bf16_t* wt;
+  long so, si, sky, skx;  // source element strides
+  int O, Op, KH, KW, I, flip;
+  long first_block;
+};
+
+__global__ void weight_prepare_kernel(const WeightDesc* __restrict__ descs, int n) {
+  int lo = 0, hi = n - 1;  // last descriptor whose first_block <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].first_block <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const WeightDesc d = descs[lo];
+  const long total = (long)d.Op * d.KH * d.KW * d.I;
+  const long e0 = ((long)blockIdx.x - d.first_block) * 2048 + threadIdx.x * 8;
+  if (e0 >= total) return;
+  const int cnt = (int)min(8L, total - e0);
+  // ---- w: index (o, ky, kx, i), i fastest
+  {
+    long t = e0;
+    int i = (int)(t % d.I); t /= d.I;
+    int kx = (int)(t % d.KW); t /= d.KW;
+    int ky = (int)(t % d.KH);
+    int o = (int)(t / d.KH);
+    float f[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      f[k] = (k < cnt && o < d.O) ? d.src[o * d.so + i * d.si + ky * d.sky + kx * d.skx] : 0.f;
+      if (++i == d.I) { i = 0; if (++kx == d.KW) { kx = 0; if (++ky == d.KH) { ky = 0; ++o; } } }
+    }
+    if (cnt == 8) *(uint4*)(d.w + e0) = pack16(f, bf16_t());
+    else for (int k = 0; k < cnt; ++k) elem<bf16_t>::st(d.w + e0 + k, f[k]);
+  }
+  // ---- wt: index (i, ky, kx, o), o fastest; source tap mirrored when flip
+  {
+    long t = e0;
+    int o = (int)(t % d.Op); t /= d.Op;
+    int kx = (int)(t % d.KW); t /= d.KW;
+    int ky = (int)(t % d.KH);
+    int i = (int)(t / d.KH);
+    float f[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int sy = d.flip ? d.KH - 1 - ky : ky, sx = d.flip ? d.KW - 1 - kx : kx;
+      f[k] = (k < cnt && o < d.O) ? d.src[o * d.so + i * d.si + sy * d.sky + sx * d.skx] : 0.f;
+      if (++o == d.Op) { o = 0; if (++kx == d.KW) { kx = 0; if (++ky == d.KH) { ky = 0; ++i; } } }
+    }
+    if (cnt == 8) *(uint4*)(d.wt + e0) = pack16(f, bf16_t());
+    else for (int k = 0; k < cnt; ++k) elem<bf16_t>::st(d.wt + e0 + k, f[k]);
+  }
+}
+
 }  // namespace
 
 #define SIHL_AFF(A, F) hipLaunchKernelGGL((affine_act_kernel<T, A, F>), dim3(g), dim3(TPB), 0, stream, (const T*)x, (T*)y, nvec, C / V, scale, shift, (const T*)res)
@@ -1507,6 +1565,17 @@ int sihl_weight_flip_transpose(const void* w, void* o, int Cout, int KH, int KW,
   else if (dtype_in == SIHL_BF16 && dtype_out == SIHL_BF16)
     hipLaunchKernelGGL((weight_flip_transpose_kernel<bf16_t, bf16_t>), dim3(g), dim3(TPB), 0, stream, (const bf16_t*)w, (bf16_t*)o, Cout, KH, KW, Cin, flip);
   else return SIHL_EARG;
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+// descs: DEVICE array of n sihl weight descriptors (layout of struct WeightDesc above, 88 bytes each; built once by
+// the host mirror), total_blocks = sum over weights of ceil(Op*KH*KW*I / 2048).
+int sihl_weight_prepare(const void* descs, int n, long total_blocks, hipStream_t stream) {
+  if (!descs || n <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffL) return SIHL_EARG;
+  static_assert(sizeof(WeightDesc) == 88, "descriptor layout is part of the C-ABI");
+  hipLaunchKernelGGL(weight_prepare_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream,
+                     (const WeightDesc*)descs, n);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
 }

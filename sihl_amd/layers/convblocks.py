@@ -66,7 +66,7 @@ class _ConvBlock(nn.Sequential):
             if bn.momentum is None or not bn.track_running_stats or not bn.affine:
                 raise NotImplementedError("BatchNorm2d with default affine / running-stat settings only")
             if self.training:
-                bn.num_batches_tracked += 1
+                ops.bump_counter(bn.num_batches_tracked)
             y = ops.conv_block(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, stride=sh,
                                pad=ph, dil=dh, act=self.act, order=self.order, training=self.training, eps=bn.eps,
                                momentum=bn.momentum)

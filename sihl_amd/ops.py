@@ -46,6 +46,34 @@ def _stream():
 
 _WS = {}
 
+# ---- BatchNorm step counters: one multi-tensor add per training step instead of one tiny kernel per layer
+_DEFERRED_COUNTERS = None
+
+
+def bump_counter(counter: Tensor) -> None:
+    """``num_batches_tracked += 1`` now, or collected for ONE fused add when inside deferred_bn_counters()."""
+    if _DEFERRED_COUNTERS is not None:
+        _DEFERRED_COUNTERS.append(counter)
+    else:
+        counter += 1
+
+
+class deferred_bn_counters:
+    """Context manager: the ~100 per-layer counter increments of a training forward become one _foreach_add_."""
+
+    def __enter__(self):
+        global _DEFERRED_COUNTERS
+        self._outer = _DEFERRED_COUNTERS
+        _DEFERRED_COUNTERS = []
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFERRED_COUNTERS
+        counters, _DEFERRED_COUNTERS = _DEFERRED_COUNTERS, self._outer
+        if counters and exc[0] is None:
+            torch._foreach_add_(counters, 1)
+        return False
+
 
 def workspace(nbytes: int, device) -> Tensor:
     """Grow-only scratch buffer per device (kernels are stream-ordered, so one buffer is shared)."""
@@ -68,7 +96,99 @@ def nchw_view(x_nhwc: Tensor) -> Tensor:
 
 def weight_khwc(w: Tensor, dtype: torch.dtype) -> Tensor:
     """(O,I,KH,KW) parameter -> contiguous [O][KH][KW][I] in the compute dtype."""
+    prep = prepared(w, dtype)
+    if prep is not None:
+        return prep.w
     return w.detach().permute(0, 2, 3, 1).to(dtype).contiguous()
+
+
+# ---- per-step operand copies of all weights (one kernel per step instead of a cast + a flip/transpose per layer)
+class _Prepared:
+    __slots__ = ("w", "wt", "version", "dtype")
+
+
+def prepared(weight: Tensor, dtype: torch.dtype):
+    """The up-to-date prepared operands of ``weight`` (see PreparedWeights), or None."""
+    prep = getattr(weight, "_sihl_prepared", None)
+    if prep is not None and prep.dtype == dtype and prep.version == weight._version:
+        return prep
+    return None
+
+
+class _WeightDesc(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("w", ctypes.c_void_p), ("wt", ctypes.c_void_p),
+                ("so", ctypes.c_int64), ("si", ctypes.c_int64), ("sky", ctypes.c_int64), ("skx", ctypes.c_int64),
+                ("O", ctypes.c_int32), ("Op", ctypes.c_int32), ("KH", ctypes.c_int32), ("KW", ctypes.c_int32),
+                ("I", ctypes.c_int32), ("flip", ctypes.c_int32), ("first_block", ctypes.c_int64)]
+
+
+class PreparedWeights:
+    """bf16 operand copies of every Conv2d / Linear weight of a model, refreshed by ONE kernel launch.
+
+    For each fp32 master weight the conv kernels need w [O][KH][KW][I] (forward, wgrad) and the flipped /
+    transposed wt [I][KH][KW][O] (dgrad) in the compute dtype.  ``refresh()`` rewrites all of them (call it after
+    every optimizer step; Trainer does) and stamps each parameter's version; conv_block / linear pick the copies up
+    while the stamp matches ``weight._version`` and fall back to their own per-layer cast otherwise (a parameter
+    changed behind the trainer's back is never read stale - as long as the change bumps the tensor's version
+    counter: in-place ops, ``copy_``, ``load_state_dict`` do; writes through ``.data`` do not, so call ``refresh()``
+    after those)."""
+
+    def __init__(self, model: torch.nn.Module, dtype: torch.dtype = torch.bfloat16):
+        if dtype != torch.bfloat16:
+            raise ValueError("prepared operands are bf16 (fp32 kernels read the master weights directly)")
+        self.dtype = dtype
+        weights = []
+        for m in model.modules():
+            if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear)) and m.weight.is_cuda and m.weight.dtype == torch.float32:
+                if all(m.weight is not w for w in weights):
+                    weights.append(m.weight)
+        self.weights = weights
+        self._table = None
+        if not weights:
+            return
+        geo = []
+        for p in weights:
+            O, I = p.shape[0], p.shape[1]
+            KH, KW = (p.shape[2], p.shape[3]) if p.dim() == 4 else (1, 1)
+            Op = (O + 7) // 8 * 8
+            geo.append((O, Op, KH, KW, I))
+        total = sum(Op * KH * KW * I for _, Op, KH, KW, I in geo)
+        dev = weights[0].device
+        self._flat = torch.zeros(2 * total + 16, dtype=dtype, device=dev)
+        descs = (_WeightDesc * len(weights))()
+        off, block = 0, 0
+        for k, (p, (O, Op, KH, KW, I)) in enumerate(zip(weights, geo)):
+            n = Op * KH * KW * I
+            w = self._flat[off: off + n].view(Op, KH, KW, I)
+            wt = self._flat[total + off: total + off + n].view(I, KH, KW, Op)
+            off += n
+            prep = _Prepared()
+            prep.w, prep.wt, prep.version, prep.dtype = w, wt, -1, dtype
+            p._sihl_prepared = prep
+            st = p.stride()
+            d = descs[k]
+            d.src, d.w, d.wt = p.data_ptr(), w.data_ptr(), wt.data_ptr()
+            d.so, d.si = st[0], st[1]
+            d.sky, d.skx = (st[2], st[3]) if p.dim() == 4 else (0, 0)
+            d.O, d.Op, d.KH, d.KW, d.I = O, Op, KH, KW, I
+            d.flip = 1 if p.dim() == 4 else 0
+            d.first_block = block
+            block += (n + 2047) // 2048
+        self._blocks = block
+        raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)
+        self._table = raw.to(dev)
+        self._ptrs = [p.data_ptr() for p in weights]
+        self.refresh()
+
+    def refresh(self) -> None:
+        if self._table is None:
+            return
+        if [p.data_ptr() for p in self.weights] != self._ptrs:
+            raise RuntimeError("a prepared weight was re-allocated; build a new PreparedWeights")
+        rc = _C.lib().sihl_weight_prepare(_p(self._table), len(self.weights), self._blocks, _stream())
+        check(rc, "sihl_weight_prepare")
+        for p in self.weights:
+            p._sihl_prepared.version = p._version
 
 
 # ----------------------------------------------------------------------------- raw kernels
@@ -203,7 +323,9 @@ class ConvBlockFn(torch.autograd.Function):
         stride, pad, dil, act, order, has_norm, training, eps, momentum, need_grad = cfg
         xd = x.detach()
         ctx.has_res = residual is not None
-        w = weight_khwc(weight, xd.dtype)
+        prep = prepared(weight, xd.dtype)
+        w = prep.w if prep is not None else weight_khwc(weight, xd.dtype)
+        ctx.wt = prep.wt if prep is not None else None  # dgrad operand, valid until the next optimizer step
         KH, KW = w.shape[1], w.shape[2]
         ctx.cfg, ctx.has_norm, ctx.kshape = cfg, has_norm, (KH, KW)
         ctx.has_bias = bias is not None
@@ -278,7 +400,7 @@ class ConvBlockFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = conv2d_wgrad_raw(x, dz, KH, KW, stride, pad, dil).permute(0, 3, 1, 2)  # (O,I,KH,KW) view
         if ctx.needs_input_grad[0]:
-            wt = weight_for_dgrad(w, flip=True)
+            wt = ctx.wt if ctx.wt is not None else weight_for_dgrad(w, flip=True)
             dx = torch.empty_like(x)
             N, H, W, Cin = x.shape
             rc = _C.lib().sihl_conv2d_dgrad(_p(dz), _p(wt), _p(dx), N, H, W, Cin, w.shape[0], KH, KW, stride, pad,
@@ -527,7 +649,11 @@ class LinearFn(torch.autograd.Function):
         rows, Cin = xd.shape
         vec = 8 if xd.dtype == torch.bfloat16 else 4
         Cout = weight.shape[0]
-        w = _pad_rows(weight.detach().to(xd.dtype), vec).contiguous()
+        prep = prepared(weight, xd.dtype)
+        if prep is not None:
+            w, ctx.wt = prep.w.view(prep.w.shape[0], -1), prep.wt  # [Cp][Cin], [Cin][1][1][Cp]
+        else:
+            w, ctx.wt = _pad_rows(weight.detach().to(xd.dtype), vec).contiguous(), None
         b = _pad_rows(bias.detach().float(), vec).contiguous() if bias is not None else None
         Cp = w.shape[0]
         y, _ = conv2d_raw(xd.view(1, 1, rows, Cin), w.view(Cp, 1, 1, Cin), b)
@@ -548,7 +674,7 @@ class LinearFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wt = weight_for_dgrad(w.view(Cp, 1, 1, Cin), flip=False)  # [Cin][1][1][Cp]
+            wt = ctx.wt if ctx.wt is not None else weight_for_dgrad(w.view(Cp, 1, 1, Cin), flip=False)  # [Cin][1][1][Cp]
             dx, _ = conv2d_raw(dy.view(1, 1, rows, Cp), wt)
             dx = dx.view(rows, Cin)
         if ctx.needs_input_grad[1]:

@@ -182,8 +182,19 @@ class Trainer:
         self.averager = GradientAverager(list(model.parameters()), group=group, bucket_mb=bucket_mb)
         self._graphs: Dict[Any, Any] = {}
         self._seen: Dict[Any, int] = {}
+        # bf16 operand copies of all conv / linear weights, rewritten by one kernel after every optimizer step
+        self.prepared = None
+        if autocast_dtype == torch.bfloat16 and on_gpu:
+            from sihl_amd import ops
+            self.prepared = ops.PreparedWeights(model, torch.bfloat16)
 
     def forward_loss(self, images: Tensor, targets: List[Any]):
+        from sihl_amd import ops  # the HIP library loads lazily: CPU oracle models never need it
+
+        with ops.deferred_bn_counters():
+            return self._forward_loss(images, targets)
+
+    def _forward_loss(self, images: Tensor, targets: List[Any]):
         dev_type = images.device.type
         if self.autocast_dtype is not None:
             # the backbone runs under autocast (ATen / MIOpen); the neck and heads take its bf16 level list
@@ -209,6 +220,8 @@ class Trainer:
             torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.grad is not None],
                                            self.grad_clip_norm)
         self.optimizer.step()
+        if self.prepared is not None:
+            self.prepared.refresh()
         # detached: a caller holding on to graph-attached metrics would keep this step's autograd graph - and its
         # AccumulateGrad nodes, which remember the stream they were created on - alive into a later graph capture
         return loss.detach(), {k: (v.detach() if isinstance(v, Tensor) else v) for k, v in metrics.items()}
@@ -224,6 +237,8 @@ class Trainer:
                 torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.grad is not None],
                                                self.grad_clip_norm)
             self.optimizer.step()
+            if self.prepared is not None:
+                self.prepared.refresh()
         leaves = [static_images] + _tree_tensors(static_targets, [])
         return graph, leaves, loss.detach(), {k: (v.detach() if isinstance(v, Tensor) else v) for k, v in metrics.items()}
 

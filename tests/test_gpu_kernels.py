@@ -204,3 +204,35 @@ def test_topk_gather_decode():
     v, i = logits.topk(K, dim=1)
     vd, idx = ops.topk_rows(logits.to(DEV), 2, 5456, K)
     assert torch.equal(idx.cpu().long(), i)
+
+
+def test_prepared_weights_match_per_layer_casts():
+    """One-launch operand preparation == the per-layer cast + flip/transpose it replaces, for channels-last and
+    plain conv weights and a narrow Linear (rows padded to the vector width); stale copies are not picked up."""
+    import torch.nn as nn
+    from sihl_amd import ops
+    torch.manual_seed(0)
+    convs = [nn.Conv2d(16, 24, 3, bias=False), nn.Conv2d(40, 8, 1, bias=False), nn.Conv2d(8, 16, 3, bias=False)]
+    lin = nn.Linear(32, 5)
+    model = nn.Sequential(*convs, lin).cuda()
+    convs[0].to(memory_format=torch.channels_last)
+    prep = ops.PreparedWeights(model)
+    assert len(prep.weights) == 4
+    for c in convs:
+        p = ops.prepared(c.weight, torch.bfloat16)
+        assert p is not None
+        want_w = c.weight.detach().permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
+        assert torch.equal(p.w, want_w)
+        assert torch.equal(p.wt, ops.weight_for_dgrad(want_w, flip=True))
+    p = ops.prepared(lin.weight, torch.bfloat16)
+    want = torch.zeros(8, 32, dtype=torch.bfloat16, device="cuda")
+    want[:5] = lin.weight.detach().to(torch.bfloat16)
+    assert torch.equal(p.w.view(8, 32), want)
+    assert torch.equal(p.wt.view(32, 8), want.t())
+    with torch.no_grad():
+        convs[1].weight.mul_(2.0)  # in-place change: the stamped version no longer matches
+    assert ops.prepared(convs[1].weight, torch.bfloat16) is None
+    assert ops.prepared(convs[0].weight, torch.float32) is None
+    prep.refresh()
+    p = ops.prepared(convs[1].weight, torch.bfloat16)
+    assert torch.equal(p.w, convs[1].weight.detach().permute(0, 2, 3, 1).to(torch.bfloat16).contiguous())
