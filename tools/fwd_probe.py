@@ -10,8 +10,10 @@ import sihl_amd  # noqa: E402
 CH = [3, 64, 256, 512, 1024, 2048]
 dev = "cuda"
 torch.manual_seed(0)
-neck = sihl_amd.layers.BiFPN(CH, 256, 3, 7).to(dev).eval()
-head = sihl_amd.heads.ObjectDetection(neck.out_channels, 80, 3, 7).to(dev).eval()
+neck = sihl_amd.layers.BiFPN(CH, 256, 3, 7).to(dev).to(memory_format=torch.channels_last).eval()
+head = sihl_amd.heads.ObjectDetection(neck.out_channels, 80, 3, 7).to(dev).to(memory_format=torch.channels_last).eval()
+from sihl_amd import ops  # noqa: E402
+prep = ops.PreparedWeights(torch.nn.ModuleList([neck, head]))  # inference: bf16 operand copies made once
 for dt in (torch.bfloat16, torch.float32):
     g = torch.Generator(device=dev).manual_seed(1)
     levels = [torch.zeros(32, 3, 512, 512, device=dev)] + [
