@@ -203,10 +203,23 @@ def main():
     lib.sihl_profile_collect(1, dt_code, ctypes.byref(nw), ctypes.byref(msw), ctypes.byref(flw), ctypes.byref(byw))
     peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
     roofline = None
+    # HBM traffic of the conv kernel per launch: PMC counters need their own rocprofv3 passes (FETCH_SIZE, WRITE_SIZE;
+    # profiles/pmc_summarize.py applies the gfx950 correction), so the figure comes from the committed summary of
+    # those passes over this same command, not from this run
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bench.json")))["kernels"]["conv_igemm_dma_kernel"]
+        if args.dtype == "bf16" and args.batch == 32 and args.size == 512:
+            traffic = pmc["traffic_MB_per_launch"] * 1e6
+    except (OSError, KeyError, ValueError):
+        pass
     if n.value:
         achieved = fl.value / (ms.value * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (NHWC implicit-GEMM conv: fwd / dgrad / linear)",
-                    "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                    "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                    "traffic_note": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_bench.json); "
+                                    "algorithmic bytes per launch: avg_algorithmic_mb_per_launch",
+                    "avg_algorithmic_mb_per_launch": by.value / n.value / 1e6,
                     "launches_per_step": n.value / profiled_steps, "avg_launch_us": ms.value * 1e3 / n.value,
                     "avg_gflop_per_launch": fl.value / n.value / 1e9,
                     "kernel_ms_per_step": ms.value / profiled_steps,
