@@ -185,6 +185,14 @@ int sihl_od_decode(const float* top_vals, const int* top_idx, const void* cls_lo
                    long* classes, float* boxes, long* num_instances, int dtype, hipStream_t stream);
 int sihl_od_anchors(const int* level_hw, int n_levels, float* offsets, float* scales, hipStream_t stream);
 
+/* ---- InstanceSegmentation mask decode (heads/instance_segmentation.py:121-163) -----------
+ * CondInst dynamic 1x1 network (10 -> 8 -> 8 -> 1, SiLU, sigmoid; 169 parameters per instance from the kernel
+ * MLP) over the mask features (B, h, w, 8) NHWC + relative coordinates, fused with the bilinear resize to
+ * (B, K, H, W).  dyn rows: w1[10][8], b1[8], w2[8][8], b2[8], w3[8], b3; dstride = elements between rows. */
+int sihl_iseg_mask_decode(const void* feats, const void* dyn, long dstride, const int* top_idx, const int* level_hw,
+                          int n_levels, int B, int K, int h, int w, int H, int W, void* out, int dtype,
+                          hipStream_t stream);
+
 /* ---- SemanticSegmentation head (heads/semantic_segmentation.py) -------------------------------------------------
  * uafm_fwd: UAFM (:163-182): out = x1*a + x2*(1-a), a = sigmoid(conv3x3_{4->1}([mean_c x1, max_c x1, mean_c x2,
  *   max_c x2]) + b); conv_w is the (1,4,3,3) weight (fp32, contiguous), conv_b one float or NULL.  stats

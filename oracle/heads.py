@@ -6,6 +6,7 @@ TEST INFRASTRUCTURE ONLY.  Reference files followed (relative to
   heads/semantic_segmentation.py:11-92       SemanticSegmentation
   heads/semantic_segmentation.py:123-182     SPPM, UAFM
   heads/multiclass_classification.py:47-52   MulticlassClassification (config-1 plumbing)
+  heads/instance_segmentation.py:15-278      InstanceSegmentation (CondInst mask decode)
 torchvision 0.21 ``ops.complete_box_iou`` / ``complete_box_iou_loss`` are NOT in
 the container; they are restated from the published CIoU definition (SURVEY.md
 App. B) and are "parity unpinned".
@@ -216,6 +217,159 @@ class ObjectDetection(nn.Module):
         loss = loc_loss + 10 * box_loss + cls_loss + iou_loss
         return loss, {"location_loss": loc_loss, "box_loss": box_loss,
                       "class_loss": cls_loss, "iou_loss": iou_loss}
+
+
+# --------------------------------------------------------------------------- instance segmentation (CondInst)
+def masks_to_boxes(masks: Tensor) -> Tensor:
+    """torchvision.ops.masks_to_boxes: (N, H, W) masks -> (N, 4) xyxy boxes of their non-zero pixels."""
+    out = torch.zeros((masks.shape[0], 4), device=masks.device, dtype=torch.float)
+    for i, m in enumerate(masks):
+        ys, xs = torch.where(m != 0)
+        out[i] = torch.stack([xs.min(), ys.min(), xs.max(), ys.max()]).float()
+    return out
+
+
+def grid_offsets(sizes: List[Tuple[int, int]], device=None) -> List[Tensor]:
+    """Per map the (h, w, 2) grid of normalised cell centres (x, y) (instance_segmentation.py:87-104)."""
+    out = []
+    for h, w in sizes:
+        ys = torch.linspace(1 / h / 2, 1 - 1 / h / 2, steps=h, device=device)
+        xs = torch.linspace(1 / w / 2, 1 - 1 / w / 2, steps=w, device=device)
+        out.append(torch.stack([xs[None, :].expand(h, w), ys[:, None].expand(h, w)], dim=2))
+    return out
+
+
+def dynamic_mask_net(feats: Tensor, weights: Tensor, c: int) -> Tensor:
+    """The per-instance 3-layer 1x1 network of CondInst: feats (n, c+2, h, w), weights (n, (c+2)c + c + cc + c + c + 1)
+    -> sigmoid masks (n, h, w) (instance_segmentation.py:139-157 / 248-260)."""
+    n = weights.shape[0]
+    i = 0
+    w1 = weights[:, i: (i := i + (c + 2) * c)].reshape(n, c + 2, c)
+    b1 = weights[:, i: (i := i + c)].reshape(n, c, 1, 1)
+    w2 = weights[:, i: (i := i + c * c)].reshape(n, c, c)
+    b2 = weights[:, i: (i := i + c)].reshape(n, c, 1, 1)
+    w3 = weights[:, i: (i := i + c)].reshape(n, c, 1)
+    b3 = weights[:, i:].reshape(n, 1, 1, 1)
+    x = F.silu(torch.einsum("nchw,ncd->ndhw", feats, w1) + b1)
+    x = F.silu(torch.einsum("nchw,ncd->ndhw", x, w2) + b2)
+    x = torch.einsum("nchw,ncd->ndhw", x, w3) + b3
+    return x.squeeze(1).sigmoid()
+
+
+class InstanceSegmentation(nn.Module):
+    """Anchor-free instance segmentation: the detector's laterals / location / class MLPs plus a kernel MLP that
+    emits, per instance, the 169 parameters of a tiny 1x1 network run over 8 mask-feature channels + 2 relative
+    coordinates of the mask level."""
+
+    def __init__(self, in_channels: List[int], num_classes: int, mask_level: int = 3, bottom_level: int = 3,
+                 top_level: int = 5, num_channels: int = 256, num_layers: int = 4, max_instances: int = 100):
+        assert num_classes > 0 and len(in_channels) > top_level
+        assert 0 < bottom_level <= top_level and num_channels % 4 == 0
+        assert num_layers >= 0 and max_instances > 0
+        super().__init__()
+        self.in_channels, self.num_classes, self.mask_level = in_channels, num_classes, mask_level
+        self.bottom_level, self.top_level = bottom_level, top_level
+        self.levels = range(bottom_level, top_level + 1)
+        self.num_channels, self.num_layers = num_channels, num_layers
+        self.max_instances, self.topk = max_instances, 9
+        self.laterals = nn.ModuleList([
+            Conv2dNormActivation(in_channels[l], num_channels, 1, activation_layer=None) for l in self.levels])
+        hidden = [num_channels] * num_layers
+
+        def mlp(out):
+            return MLP(num_channels, hidden + [out], norm_layer=nn.LayerNorm, activation_layer=nn.SiLU)
+
+        self.loc_head = mlp(1)
+        self.loc_head[-2].bias.data.fill_(-5.0)
+        self.cls_head = mlp(num_classes)
+        c = self.mask_num_channels = 8
+        self.kernel_head = mlp((c + 2) * c + c + c * c + c + c + 1)
+        self.mask_lateral = Conv2dNormActivation(in_channels[mask_level], num_channels, 1, activation_layer=None)
+        self.mask_head = Conv2dNormActivation(num_channels, c, 3, activation_layer=nn.SiLU)
+        scale = 2 ** bottom_level
+        self.output_shapes = {"num_instances": ("batch_size",), "scores": ("batch_size", max_instances),
+                              "classes": ("batch_size", max_instances),
+                              "masks": ("batch_size", max_instances, f"height/{scale}", f"width/{scale}")}
+
+    def _flat_feats(self, inputs: List[Tensor]) -> Tensor:
+        feats = [lat(inputs[l]) for l, lat in zip(self.levels, self.laterals)]
+        return torch.cat([f.flatten(2).transpose(1, 2) for f in feats], dim=1)
+
+    def _sizes(self, inputs: List[Tensor]) -> List[Tuple[int, int]]:
+        return [tuple(inputs[l].shape[2:]) for l in self.levels]
+
+    def forward(self, inputs: List[Tensor]):
+        B, _, H, W = inputs[0].shape
+        K, c, dev = self.max_instances, self.mask_num_channels, inputs[0].device
+        flat = self._flat_feats(inputs)
+        loc_logits, idx = self.loc_head(flat).squeeze(2).topk(K, dim=1)
+        rows = torch.arange(B)[:, None].expand(B, K)
+        scores = loc_logits.sigmoid()
+        num_instances = (scores > 0.5).sum(dim=1)
+        sel = flat[rows, idx]
+        mask_feats = self.mask_head(self.mask_lateral(inputs[self.mask_level]))  # (B, c, h, w)
+        h, w = mask_feats.shape[2:]
+        offsets = torch.cat([g.reshape(-1, 2) for g in grid_offsets(self._sizes(inputs), dev)])[idx]  # (B, K, 2)
+        grid = grid_offsets([(h, w)], dev)[0].permute(2, 0, 1)  # (2, h, w)
+        rel = grid[None, None] - offsets[:, :, :, None, None]
+        feats = torch.cat([mask_feats[:, None].expand(B, K, c, h, w), rel], dim=2)
+        masks = dynamic_mask_net(feats.reshape(B * K, c + 2, h, w), self.kernel_head(sel).reshape(B * K, -1), c)
+        classes = self.cls_head(sel).max(dim=2).indices
+        masks = F.interpolate(masks.reshape(B, K, h, w), size=(H, W), mode="bilinear")
+        return num_instances, scores, classes, masks
+
+    def training_step(self, inputs: List[Tensor], classes: List[Tensor], masks: List[Tensor],
+                      is_validating: bool = False):
+        assert len(inputs) > self.top_level
+        dev = inputs[0].device
+        B, _, H, W = inputs[0].shape
+        c = self.mask_num_channels
+        valid = [m.any((1, 2)) if m.shape[0] > 0 else None for m in masks]  # drop empty masks (:178-181)
+        classes = [cl[v] for v, cl in zip(valid, classes)]
+        masks = [m[v] for v, m in zip(valid, masks)]
+        grids = grid_offsets(self._sizes(inputs), dev)
+        centres = torch.cat([g.reshape(-1, 2) for g in grids])  # (P, 2)
+        half = torch.cat([torch.tensor([-0.5 / w_, -0.5 / h_, 0.5 / w_, 0.5 / h_], device=dev).expand(h_ * w_, 4)
+                          for h_, w_ in self._sizes(inputs)])
+        anchors = (centres.repeat(1, 2) + half) * torch.tensor([[W, H, W, H]], device=dev)
+        boxes = [masks_to_boxes(m) for m in masks]
+        matches = [bbox_matching(anchors, boxes[b], self.topk, relative=True) for b in range(B)]
+        assignment = torch.stack([m[0] for m in matches])
+        rel_iou = torch.stack([m[1] for m in matches])
+
+        flat = self._flat_feats(inputs)
+        o2m = rel_iou > 0
+        wts = rel_iou[o2m]
+        sel = flat[o2m]
+        loc_logits = self.loc_head(flat).squeeze(2)
+        loc_target = (rel_iou == 1.0).to(torch.float32)
+        loc_loss = F.binary_cross_entropy_with_logits(loc_logits.float(), loc_target, reduction="none")
+        loc_loss = loc_loss.sum() / loc_target.sum()
+        z = torch.zeros_like(loc_loss)
+        if rel_iou.max() == 0:
+            return loc_loss, {"location_loss": loc_loss, "mask_loss": z, "class_loss": z}
+
+        mask_feats = self.mask_head(self.mask_lateral(inputs[self.mask_level]))
+        h, w = mask_feats.shape[2:]
+        grid = grid_offsets([(h, w)], dev)[0].permute(2, 0, 1)
+        per_image = []
+        for b in range(B):
+            idx = o2m[b].nonzero()[:, 0]
+            if idx.numel():
+                rel = grid[None] - centres[idx][:, :, None, None]
+                per_image.append(torch.cat([mask_feats[b][None].expand(idx.numel(), c, h, w), rel], dim=1))
+        preds = dynamic_mask_net(torch.cat(per_image), self.kernel_head(sel), c)
+        target = torch.cat([masks[b][assignment[b, m]] for b, m in enumerate(o2m) if m.any()]).to(preds)
+        target = F.interpolate(target.unsqueeze(1), size=preds.shape[1:], mode="bilinear").squeeze(1)
+        num = (preds * target).sum((1, 2))
+        den = (preds ** 2 + target ** 2).sum((1, 2))
+        mask_loss = 1 - 2 * num.float() / den
+        mask_loss = (wts * mask_loss).sum() / wts.sum()
+        cls_target = torch.cat([classes[b][assignment[b, m]] for b, m in enumerate(o2m) if m.any()])
+        cls_loss = F.cross_entropy(self.cls_head(sel).float(), cls_target, reduction="none")
+        cls_loss = (wts * cls_loss).sum() / wts.sum()
+        loss = loc_loss + 10 * mask_loss + cls_loss
+        return loss, {"location_loss": loc_loss, "mask_loss": mask_loss, "class_loss": cls_loss}
 
 
 # --------------------------------------------------------------------------- SemSeg head

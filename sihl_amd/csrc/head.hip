@@ -98,6 +98,107 @@ __global__ void od_decode_kernel(const float* __restrict__ top_vals, const int* 
   boxes[(long)i * 4 + 3] = (oy + hy * expf(elem<T>::ld(br + 3))) * full_h;
 }
 
+// ------------------------------------------------------------------ CondInst mask decode (instance segmentation)
+// Per instance (b, k): a 3-layer 1x1 network whose 169 parameters were emitted by the kernel MLP runs over the 8
+// mask-feature channels + 2 coordinates relative to the instance's location, at the mask level (h x w); sigmoid;
+// bilinear resize (align_corners = False) to the full H x W.  The reference materialises (B, K, 10, h, w), three
+// einsum results and the low-resolution masks before F.interpolate (instance_segmentation.py:121-163); here a
+// workgroup owns one 64 x 64 OUTPUT tile of one instance, evaluates the network for the low-resolution pixels that
+// tile interpolates from (into LDS) and writes the tile: the only HBM traffic besides the (tiny) inputs is the
+// output itself.  Parameter layout of a row: w1[10][8], b1[8], w2[8][8], b2[8], w3[8], b3.
+constexpr int ISEG_C = 8, ISEG_NP = (ISEG_C + 2) * ISEG_C + ISEG_C + ISEG_C * ISEG_C + ISEG_C + ISEG_C + 1;
+constexpr int ISEG_OT = 64, ISEG_LOW = ISEG_OT + 3;
+
+__device__ __forceinline__ float iseg_sigmoid(float v) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fminf(-v * 1.4426950408889634f, 126.f)));
+}
+
+template <typename T>
+__global__ void iseg_mask_decode_kernel(const T* __restrict__ feats, const T* __restrict__ dyn, long dstride,
+                                        const int* __restrict__ top_idx, Levels lv, int K, int h, int w, int H,
+                                        int W, int tiles_x, int tiles_y, T* __restrict__ out) {
+  __shared__ float par[ISEG_NP + 2];
+  __shared__ float low[ISEG_LOW * ISEG_LOW];
+  const int tile = blockIdx.x % (tiles_x * tiles_y), inst = blockIdx.x / (tiles_x * tiles_y);
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x, b = inst / K;
+  for (int i = threadIdx.x; i < ISEG_NP; i += blockDim.x) par[i] = elem<T>::ld(dyn + (long)inst * dstride + i);
+  if (threadIdx.x == 0) {  // normalised centre of the instance's pyramid position
+    int p = top_idx[inst], l = 0;
+    while (l < lv.n - 1 && p >= lv.h[l] * lv.w[l]) { p -= lv.h[l] * lv.w[l]; ++l; }
+    const int cy = p / lv.w[l], cx = p - cy * lv.w[l];
+    par[ISEG_NP] = (cx + 0.5f) / lv.w[l];
+    par[ISEG_NP + 1] = (cy + 0.5f) / lv.h[l];
+  }
+  // low-resolution window this output tile reads
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  const int oy0 = ty * ISEG_OT, ox0 = tx * ISEG_OT;
+  const int oy1 = min(oy0 + ISEG_OT, H), ox1 = min(ox0 + ISEG_OT, W);
+  const int ly0 = (int)fmaxf(sy * (oy0 + 0.5f) - 0.5f, 0.f), lx0 = (int)fmaxf(sx * (ox0 + 0.5f) - 0.5f, 0.f);
+  const int ly1 = min(h - 1, (int)fmaxf(sy * (oy1 - 0.5f) - 0.5f, 0.f) + 1);
+  const int lx1 = min(w - 1, (int)fmaxf(sx * (ox1 - 0.5f) - 0.5f, 0.f) + 1);
+  const int nly = ly1 - ly0 + 1, nlx = lx1 - lx0 + 1;
+  __syncthreads();
+  const float ox = par[ISEG_NP], oy = par[ISEG_NP + 1];
+  const float* w1 = par;
+  const float* b1 = w1 + (ISEG_C + 2) * ISEG_C;
+  const float* w2 = b1 + ISEG_C;
+  const float* b2 = w2 + ISEG_C * ISEG_C;
+  const float* w3 = b2 + ISEG_C;
+  const float b3 = w3[ISEG_C];
+  for (int i = threadIdx.x; i < nly * nlx; i += blockDim.x) {
+    const int ry = i / nlx, rx = i - ry * nlx, y = ly0 + ry, x = lx0 + rx;
+    float in[ISEG_C + 2];
+    const T* f = feats + (((long)b * h + y) * w + x) * ISEG_C;
+#pragma unroll
+    for (int c = 0; c < ISEG_C; ++c) in[c] = elem<T>::ld(f + c);
+    in[ISEG_C] = (x + 0.5f) / w - ox;
+    in[ISEG_C + 1] = (y + 0.5f) / h - oy;
+    float a[ISEG_C], a2[ISEG_C];
+#pragma unroll
+    for (int d = 0; d < ISEG_C; ++d) {
+      float t = b1[d];
+#pragma unroll
+      for (int c = 0; c < ISEG_C + 2; ++c) t += in[c] * w1[c * ISEG_C + d];
+      a[d] = t * iseg_sigmoid(t);
+    }
+#pragma unroll
+    for (int d = 0; d < ISEG_C; ++d) {
+      float t = b2[d];
+#pragma unroll
+      for (int c = 0; c < ISEG_C; ++c) t += a[c] * w2[c * ISEG_C + d];
+      a2[d] = t * iseg_sigmoid(t);
+    }
+    float t = b3;
+#pragma unroll
+    for (int c = 0; c < ISEG_C; ++c) t += a2[c] * w3[c];
+    low[ry * ISEG_LOW + rx] = iseg_sigmoid(t);
+  }
+  __syncthreads();
+  // bilinear write of the tile: a thread owns 8 consecutive output columns of rows (tid / 8) + 32 j
+  const int cx8 = (threadIdx.x & 7) * 8;
+  for (int r = threadIdx.x >> 3; r < oy1 - oy0; r += blockDim.x >> 3) {
+    const int oyy = oy0 + r;
+    const float fy = fmaxf(sy * (oyy + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)fy, y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    const float wy1 = fy - y0, wy0 = 1.f - wy1;
+    const float* r0 = low + (y0 - ly0) * ISEG_LOW;
+    const float* r1 = low + (y1 - ly0) * ISEG_LOW;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int oxx = min(ox0 + cx8 + e, W - 1);
+      const float fx = fmaxf(sx * (oxx + 0.5f) - 0.5f, 0.f);
+      const int x0 = (int)fx, x1 = x0 + (x0 < w - 1 ? 1 : 0);
+      const float wx1 = fx - x0, wx0 = 1.f - wx1;
+      v[e] = wy0 * (wx0 * r0[x0 - lx0] + wx1 * r0[x1 - lx0]) + wy1 * (wx0 * r1[x0 - lx0] + wx1 * r1[x1 - lx0]);
+    }
+    T* o = out + ((long)inst * H + oyy) * W + ox0 + cx8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (ox0 + cx8 + e < ox1) elem<T>::st(o + e, v[e]);
+  }
+}
+
 // offsets (cx,cy,cx,cy) and scales (-1/2w,-1/2h,1/2w,1/2h) for every pyramid position (training-side anchors)
 __global__ void od_anchors_kernel(Levels lv, int P, float* __restrict__ offsets, float* __restrict__ scales) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -187,6 +288,29 @@ int sihl_od_anchors(const int* level_hw, int n_levels, float* offsets, float* sc
   int P = 0;
   for (int i = 0; i < n_levels; ++i) { lv.h[i] = level_hw[2 * i]; lv.w[i] = level_hw[2 * i + 1]; P += lv.h[i] * lv.w[i]; }
   hipLaunchKernelGGL(od_anchors_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, lv, P, offsets, scales);
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+// masks (B, K, H, W) from mask features (B, h, w, 8) NHWC, per-instance parameter rows dyn[(b*K+k)*dstride .. +169)
+// and the instances' pyramid positions top_idx (B, K) (level_hw as in sihl_od_decode).  All tensors dtype.
+int sihl_iseg_mask_decode(const void* feats, const void* dyn, long dstride, const int* top_idx, const int* level_hw,
+                          int n_levels, int B, int K, int h, int w, int H, int W, void* out, int dtype,
+                          hipStream_t stream) {
+  if (!feats || !dyn || !top_idx || !level_hw || !out || n_levels <= 0 || n_levels > 8 || B <= 0 || K <= 0 ||
+      h <= 0 || w <= 0 || H < h || W < w || dstride < ISEG_NP)
+    return SIHL_EARG;
+  Levels lv;
+  lv.n = n_levels;
+  for (int i = 0; i < n_levels; ++i) { lv.h[i] = level_hw[2 * i]; lv.w[i] = level_hw[2 * i + 1]; }
+  const int tiles_x = (W + ISEG_OT - 1) / ISEG_OT, tiles_y = (H + ISEG_OT - 1) / ISEG_OT;
+  const long blocks = (long)B * K * tiles_x * tiles_y;
+  if (blocks > 0x7fffffffL) return SIHL_EARG;
+  if (dtype == SIHL_F32)
+    hipLaunchKernelGGL(iseg_mask_decode_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)feats, (const float*)dyn, dstride, top_idx, lv, K, h, w, H, W, tiles_x, tiles_y, (float*)out);
+  else if (dtype == SIHL_BF16)
+    hipLaunchKernelGGL(iseg_mask_decode_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)feats, (const bf16_t*)dyn, dstride, top_idx, lv, K, h, w, H, W, tiles_x, tiles_y, (bf16_t*)out);
+  else return SIHL_EARG;
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
 }

@@ -765,6 +765,25 @@ def od_decode(top_vals, top_idx, cls_logits, box_raw, level_hw, full_wh):
     return num, scores, classes, boxes
 
 
+def iseg_mask_decode(mask_feats: Tensor, dyn: Tensor, top_idx: Tensor, level_hw, out_hw) -> Tensor:
+    """CondInst masks (B, K, H, W): mask_feats (B, h, w, 8) NHWC, dyn (B*K, 169) parameter rows (any row stride),
+    top_idx (B, K) int32 pyramid positions; dynamic 10->8->8->1 network + sigmoid + bilinear resize in one kernel."""
+    _require_gpu(mask_feats)
+    B, h, w, c = mask_feats.shape
+    K = top_idx.shape[1]
+    if c != 8 or dyn.shape[-1] != 169 or dyn.dtype != mask_feats.dtype or dyn.stride(-1) != 1:
+        raise ValueError("iseg_mask_decode: 8 mask channels and contiguous 169-parameter rows of the same dtype")
+    mask_feats = mask_feats.contiguous()
+    dyn2 = dyn.reshape(B * K, 169) if dyn.dim() != 2 else dyn
+    H, W = int(out_hw[0]), int(out_hw[1])
+    out = torch.empty((B, K, H, W), dtype=mask_feats.dtype, device=mask_feats.device)
+    rc = _C.lib().sihl_iseg_mask_decode(_p(mask_feats), _p(dyn2), dyn2.stride(0), _p(top_idx.contiguous()),
+                                        _levels_arr(level_hw), len(level_hw), B, K, h, w, H, W, _p(out),
+                                        _dt(mask_feats), _stream())
+    check(rc, "sihl_iseg_mask_decode")
+    return out
+
+
 def od_anchors(level_hw, device):
     P = sum(h * w for h, w in level_hw)
     offsets = torch.empty((P, 4), dtype=torch.float32, device=device)

@@ -339,3 +339,54 @@ def _uafm_case():
 
 _sppm_case()
 _uafm_case()
+
+
+# ------------------------------------------------------------------ instance-segmentation head
+_IS_CH = [3] + [32] * 5
+
+
+def _is_build(ns):
+    return perturb_(ns.InstanceSegmentation(_IS_CH, num_classes=6, mask_level=3, bottom_level=3, top_level=5,
+                                            num_channels=32, num_layers=2, max_instances=12), 21, scale=0.6)
+
+
+def _is_inputs(seed=95):
+    return {"levels": _levels(seed, 2, _IS_CH, 64, range(3, 6))}
+
+
+def _is_forward_run(m, inp):
+    with torch.no_grad():
+        n, scores, classes, masks = m(inp["levels"])
+    return {"num_instances": n, "scores": scores, "classes": classes, "masks": masks}
+
+
+_register("iseg_forward_eval", _is_build, _is_inputs, _is_forward_run, False, needs="iseg")
+
+
+def iseg_targets():
+    """2 images: two objects (one of them with an EMPTY mask, dropped by the head) and one object."""
+    m0 = torch.zeros(3, 64, 64)
+    m0[0, 8:30, 10:40] = 1.0
+    m0[1, 30:60, 24:56] = 1.0
+    m1 = torch.zeros(1, 64, 64)
+    m1[0, 4:44, 12:36] = 1.0
+    return [torch.tensor([2, 4, 1]), torch.tensor([5])], [m0, m1]
+
+
+def _is_train_run(m, inp):
+    lv = [t.clone().requires_grad_(i >= 3) for i, t in enumerate(inp["levels"])]
+    dev = lv[3].device
+    classes, masks = iseg_targets()
+    loss, metrics = m.training_step(lv, [c.to(dev) for c in classes], [k.to(dev) for k in masks])
+    res = {"loss": loss, **{k: v for k, v in metrics.items()}}
+    params = [(n, p) for n, p in m.named_parameters()]
+    g = torch.autograd.grad(loss, lv[3:] + [p for _, p in params], allow_unused=True)
+    for i, gi in enumerate(g[:3]):
+        res[f"gin{i}"] = gi
+    for (n, _), gp in zip(params, g[3:]):
+        if gp is not None:
+            res[f"gp.{n}"] = gp
+    return res
+
+
+_register("iseg_training_step", _is_build, _is_inputs, _is_train_run, True, needs="iseg")

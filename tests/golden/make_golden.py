@@ -11,7 +11,7 @@ imported (torchvision / torchmetrics / timm / lightning are absent), so bare
 package objects are registered for ``sihl``, ``sihl.layers`` and ``sihl.heads``
 and each hot-path file is executed with importlib from where it lies:
   layers/{convblocks,pooling,scalers,bifpn}.py  - need only torch/einops/numpy: run UNMODIFIED
-  layers/fpn.py, heads/object_detection.py, heads/semantic_segmentation.py
+  layers/fpn.py, heads/object_detection.py, heads/semantic_segmentation.py, heads/instance_segmentation.py
       - additionally import ``torchvision.ops`` / ``torchmetrics``.  Stand-in modules are
         registered for those imports: ``ops.Conv2dNormActivation`` / ``ops.MLP`` (compositions
         of torch.nn layers, documented structure) and ``ops.complete_box_iou[_loss]`` (published
@@ -65,6 +65,7 @@ def load_reference():
     ops.Conv2dNormActivation, ops.MLP = ol.Conv2dNormActivation, ol.MLP
     ops.complete_box_iou = oh.complete_box_iou
     ops.complete_box_iou_loss = lambda a, b, reduction="none", eps=1e-7: oh.complete_box_iou_loss(a, b, eps)
+    ops.masks_to_boxes = oh.masks_to_boxes
     tv.ops = ops
     sys.modules["torchvision"], sys.modules["torchvision.ops"] = tv, ops
     tm = types.ModuleType("torchmetrics")
@@ -83,7 +84,7 @@ def load_reference():
             if isinstance(v, type) and v.__module__ == mod.__name__:
                 setattr(layers, k, v)
                 setattr(ns, k, v)
-    for name in ("object_detection", "semantic_segmentation"):
+    for name in ("object_detection", "semantic_segmentation", "instance_segmentation"):
         mod = _load(f"sihl.heads.{name}", f"heads/{name}.py")
         for k, v in vars(mod).items():
             if isinstance(v, type) and v.__module__ == mod.__name__:
@@ -102,7 +103,7 @@ def _flatten(prefix, obj, out):
 
 
 PINNED = {"layers": "reference-unmodified", "fpn": "reference+tv-standins",
-          "od": "reference+tv-standins", "semseg": "reference+tv-standins"}
+          "od": "reference+tv-standins", "semseg": "reference+tv-standins", "iseg": "reference+tv-standins"}
 
 
 def main(argv):

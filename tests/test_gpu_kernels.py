@@ -236,3 +236,39 @@ def test_prepared_weights_match_per_layer_casts():
     prep.refresh()
     p = ops.prepared(convs[1].weight, torch.bfloat16)
     assert torch.equal(p.w, convs[1].weight.detach().permute(0, 2, 3, 1).to(torch.bfloat16).contiguous())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1.5e-2)])
+@pytest.mark.parametrize("B,K,h,w,H,W", [(2, 7, 9, 13, 72, 104), (1, 3, 4, 4, 4, 4), (2, 100, 32, 32, 256, 256)])
+def test_iseg_mask_decode_matches_torch(dtype, tol, B, K, h, w, H, W):
+    """Fused CondInst decode (dynamic 10->8->8->1 network + sigmoid + bilinear resize) vs the einsum / F.interpolate
+    formulation of the reference (instance_segmentation.py:121-163), incl. ragged tiles and identity resize."""
+    import torch.nn.functional as F
+    from sihl_amd import ops
+    torch.manual_seed(3)
+    level_hw = [(h, w), (max(1, h // 2), max(1, w // 2))]
+    P = sum(a * b for a, b in level_hw)
+    feats = torch.randn(B, h, w, 8, device="cuda").to(dtype)
+    dyn = (torch.randn(B * K, 176, device="cuda") * 0.7).to(dtype)[:, :169]  # strided rows, as the padded Linear gives
+    idx = torch.randint(0, P, (B, K), device="cuda", dtype=torch.int32)
+    got = ops.iseg_mask_decode(feats, dyn, idx, level_hw, (H, W))
+    assert got.shape == (B, K, H, W) and got.dtype == dtype
+    # reference formulation in fp32 on the same (rounded) operands
+    f32, d32 = feats.float(), dyn.float()
+    cen = []
+    for a, b in level_hw:
+        ys, xs = (torch.arange(a, device="cuda") + 0.5) / a, (torch.arange(b, device="cuda") + 0.5) / b
+        cen.append(torch.stack([xs[None, :].expand(a, b), ys[:, None].expand(a, b)], 2).reshape(-1, 2))
+    off = torch.cat(cen)[idx.long()]  # (B, K, 2)
+    ys, xs = (torch.arange(h, device="cuda") + 0.5) / h, (torch.arange(w, device="cuda") + 0.5) / w
+    grid = torch.stack([xs[None, :].expand(h, w), ys[:, None].expand(h, w)])
+    x = torch.cat([f32.permute(0, 3, 1, 2)[:, None].expand(B, K, 8, h, w), grid[None, None] - off[..., None, None]], 2)
+    x = x.reshape(B * K, 10, h, w)
+    w1, b1 = d32[:, :80].reshape(-1, 10, 8), d32[:, 80:88].reshape(-1, 8, 1, 1)
+    w2, b2 = d32[:, 88:152].reshape(-1, 8, 8), d32[:, 152:160].reshape(-1, 8, 1, 1)
+    w3, b3 = d32[:, 160:168].reshape(-1, 8, 1), d32[:, 168:].reshape(-1, 1, 1, 1)
+    x = F.silu(torch.einsum("nchw,ncd->ndhw", x, w1) + b1)
+    x = F.silu(torch.einsum("nchw,ncd->ndhw", x, w2) + b2)
+    x = (torch.einsum("nchw,ncd->ndhw", x, w3) + b3).sigmoid()
+    want = F.interpolate(x.reshape(B, K, h, w), size=(H, W), mode="bilinear")
+    torch.testing.assert_close(got.float(), want, rtol=tol, atol=tol)
