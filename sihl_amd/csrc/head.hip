@@ -107,14 +107,14 @@ __global__ void od_decode_kernel(const float* __restrict__ top_vals, const int* 
 // tile interpolates from (into LDS) and writes the tile: the only HBM traffic besides the (tiny) inputs is the
 // output itself.  Parameter layout of a row: w1[10][8], b1[8], w2[8][8], b2[8], w3[8], b3.
 constexpr int ISEG_C = 8, ISEG_NP = (ISEG_C + 2) * ISEG_C + ISEG_C + ISEG_C * ISEG_C + ISEG_C + ISEG_C + 1;
-constexpr int ISEG_OT = 64, ISEG_LOW = ISEG_OT + 3;
+constexpr int ISEG_LOW = 64 + 3;  // low-resolution window edge a tile may need (64 x 64 tile at scale 1; 128 x 128 at <= 1/2)
 
 __device__ __forceinline__ float iseg_sigmoid(float v) {
   return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fminf(-v * 1.4426950408889634f, 126.f)));
 }
 
-template <typename T>
-__global__ void iseg_mask_decode_kernel(const T* __restrict__ feats, const T* __restrict__ dyn, long dstride,
+template <typename T, int ISEG_OT>
+__global__ void __launch_bounds__(256) iseg_mask_decode_kernel(const T* __restrict__ feats, const T* __restrict__ dyn, long dstride,
                                         const int* __restrict__ top_idx, Levels lv, int K, int h, int w, int H,
                                         int W, int tiles_x, int tiles_y, T* __restrict__ out) {
   __shared__ float par[ISEG_NP + 2];
@@ -146,6 +146,8 @@ __global__ void iseg_mask_decode_kernel(const T* __restrict__ feats, const T* __
   const float* w3 = b2 + ISEG_C;
   const float b3 = w3[ISEG_C];
   for (int i = threadIdx.x; i < nly * nlx; i += blockDim.x) {
+    // the 169 parameters stay in LDS: hoisting them out of this (usually single-trip) loop into registers spilled
+    asm volatile("" ::: "memory");
     const int ry = i / nlx, rx = i - ry * nlx, y = ly0 + ry, x = lx0 + rx;
     float in[ISEG_C + 2];
     const T* f = feats + (((long)b * h + y) * w + x) * ISEG_C;
@@ -174,9 +176,23 @@ __global__ void iseg_mask_decode_kernel(const T* __restrict__ feats, const T* __
     low[ry * ISEG_LOW + rx] = iseg_sigmoid(t);
   }
   __syncthreads();
-  // bilinear write of the tile: a thread owns 8 consecutive output columns of rows (tid / 8) + 32 j
-  const int cx8 = (threadIdx.x & 7) * 8;
-  for (int r = threadIdx.x >> 3; r < oy1 - oy0; r += blockDim.x >> 3) {
+  // bilinear write of the tile: a thread owns 8 consecutive output columns (their x taps are row-independent and
+  // computed once) of rows (tid / 8) + 32 j; full 8-column groups leave as 16-byte stores
+  constexpr int CG = ISEG_OT / 8;  // 8-column groups per tile row
+  const int cx8 = (threadIdx.x % CG) * 8;
+  int xa[8], xb[8];
+  float wxb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int oxx = min(ox0 + cx8 + e, W - 1);
+    const float fx = fmaxf(sx * (oxx + 0.5f) - 0.5f, 0.f);
+    const int x0 = (int)fx;
+    xa[e] = x0 - lx0;
+    xb[e] = x0 + (x0 < w - 1 ? 1 : 0) - lx0;
+    wxb[e] = fx - x0;
+  }
+  const bool full = ox0 + cx8 + 8 <= ox1 && (W % 8) == 0;
+  for (int r = threadIdx.x / CG; r < oy1 - oy0; r += blockDim.x / CG) {
     const int oyy = oy0 + r;
     const float fy = fmaxf(sy * (oyy + 0.5f) - 0.5f, 0.f);
     const int y0 = (int)fy, y1 = y0 + (y0 < h - 1 ? 1 : 0);
@@ -186,16 +202,22 @@ __global__ void iseg_mask_decode_kernel(const T* __restrict__ feats, const T* __
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int oxx = min(ox0 + cx8 + e, W - 1);
-      const float fx = fmaxf(sx * (oxx + 0.5f) - 0.5f, 0.f);
-      const int x0 = (int)fx, x1 = x0 + (x0 < w - 1 ? 1 : 0);
-      const float wx1 = fx - x0, wx0 = 1.f - wx1;
-      v[e] = wy0 * (wx0 * r0[x0 - lx0] + wx1 * r0[x1 - lx0]) + wy1 * (wx0 * r1[x0 - lx0] + wx1 * r1[x1 - lx0]);
+      const float wxa = 1.f - wxb[e];  // same association as ATen's upsample_bilinear2d
+      v[e] = wy0 * (wxa * r0[xa[e]] + wxb[e] * r0[xb[e]]) + wy1 * (wxa * r1[xa[e]] + wxb[e] * r1[xb[e]]);
     }
     T* o = out + ((long)inst * H + oyy) * W + ox0 + cx8;
+    if (full) {
+      if constexpr (sizeof(T) == 2) {
+        *(uint4*)o = pack16(v, T());
+      } else {
+        *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+    } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
-      if (ox0 + cx8 + e < ox1) elem<T>::st(o + e, v[e]);
+      for (int e = 0; e < 8; ++e)
+        if (ox0 + cx8 + e < ox1) elem<T>::st(o + e, v[e]);
+    }
   }
 }
 
@@ -303,13 +325,15 @@ int sihl_iseg_mask_decode(const void* feats, const void* dyn, long dstride, cons
   Levels lv;
   lv.n = n_levels;
   for (int i = 0; i < n_levels; ++i) { lv.h[i] = level_hw[2 * i]; lv.w[i] = level_hw[2 * i + 1]; }
-  const int tiles_x = (W + ISEG_OT - 1) / ISEG_OT, tiles_y = (H + ISEG_OT - 1) / ISEG_OT;
+  // 128 x 128 output tiles when the low-resolution window they interpolate from still fits the LDS table
+  const int ot = (2 * h <= H && 2 * w <= W) ? 128 : 64;
+  const int tiles_x = (W + ot - 1) / ot, tiles_y = (H + ot - 1) / ot;
   const long blocks = (long)B * K * tiles_x * tiles_y;
   if (blocks > 0x7fffffffL) return SIHL_EARG;
-  if (dtype == SIHL_F32)
-    hipLaunchKernelGGL(iseg_mask_decode_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)feats, (const float*)dyn, dstride, top_idx, lv, K, h, w, H, W, tiles_x, tiles_y, (float*)out);
-  else if (dtype == SIHL_BF16)
-    hipLaunchKernelGGL(iseg_mask_decode_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)feats, (const bf16_t*)dyn, dstride, top_idx, lv, K, h, w, H, W, tiles_x, tiles_y, (bf16_t*)out);
+#define SIHL_ISEG(T, OT) hipLaunchKernelGGL((iseg_mask_decode_kernel<T, OT>), dim3((unsigned)blocks), dim3(256), 0, stream, (const T*)feats, (const T*)dyn, dstride, top_idx, lv, K, h, w, H, W, tiles_x, tiles_y, (T*)out)
+  if (dtype == SIHL_F32) { if (ot == 128) SIHL_ISEG(float, 128); else SIHL_ISEG(float, 64); }
+  else if (dtype == SIHL_BF16) { if (ot == 128) SIHL_ISEG(bf16_t, 128); else SIHL_ISEG(bf16_t, 64); }
+#undef SIHL_ISEG
   else return SIHL_EARG;
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
