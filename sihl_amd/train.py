@@ -168,7 +168,8 @@ class Trainer:
 
     def __init__(self, model: nn.Module, optimizer: Optional[torch.optim.Optimizer] = None, group=None,
                  grad_clip_norm: Optional[float] = 0.1, autocast_dtype: Optional[torch.dtype] = None,
-                 bucket_mb: float = 32.0, graph: bool = False, **opt_kw):
+                 bucket_mb: float = 32.0, graph: bool = False, scheduler=None,
+                 scheduler_kwargs: Optional[Dict[str, Any]] = None, **opt_kw):
         self.model = model
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         on_gpu = all(p.is_cuda for p in model.parameters())
@@ -182,11 +183,55 @@ class Trainer:
         self.averager = GradientAverager(list(model.parameters()), group=group, bucket_mb=bucket_mb)
         self._graphs: Dict[Any, Any] = {}
         self._seen: Dict[Any, int] = {}
+        self.scheduler = self._make_scheduler(scheduler, dict(scheduler_kwargs or {}))
         # bf16 operand copies of all conv / linear weights, rewritten by one kernel after every optimizer step
         self.prepared = None
         if autocast_dtype == torch.bfloat16 and on_gpu:
             from sihl_amd import ops
             self.prepared = ops.PreparedWeights(model, torch.bfloat16)
+
+    def _make_scheduler(self, scheduler, kw: Dict[str, Any]):
+        """Per-step learning-rate schedule of the reference (lightning_module.py:226-241): ``scheduler(optimizer,
+        **kwargs)``, preceded by a LinearLR warm-up (start factor 0.01) of ``kwargs["warmup"]`` steps when given.
+
+        In graph mode the optimizer reads its learning rates from device tensors (a replay cannot see a changed
+        Python float): the schedule then runs on a parameter-free shadow optimizer with the same groups and its
+        values are written into those tensors before every replay."""
+        self._lr_tensors = None
+        if scheduler is None:
+            return None
+        target = self.optimizer
+        if self.use_graph:
+            self._lr_tensors = []
+            shadow_groups = []
+            for g in self.optimizer.param_groups:
+                dev = g["params"][0].device
+                t = torch.tensor(float(g["lr"]), dtype=torch.float32, device=dev)
+                shadow_groups.append({"params": [torch.zeros((), requires_grad=True)], "lr": float(g["lr"])})
+                g["lr"] = t
+                self._lr_tensors.append(t)
+            target = torch.optim.SGD(shadow_groups, lr=1.0)
+        warmup = kw.pop("warmup", None)
+        sched = scheduler(target, **kw)
+        if warmup:
+            lrs = torch.optim.lr_scheduler
+            sched = lrs.SequentialLR(target, [lrs.LinearLR(target, start_factor=0.01, total_iters=warmup), sched],
+                                     milestones=[warmup])
+        self._shadow = target if self.use_graph else None
+        self._push_lrs()
+        return sched
+
+    def _push_lrs(self) -> None:
+        if self._lr_tensors is not None:
+            for t, g in zip(self._lr_tensors, self._shadow.param_groups):
+                t.fill_(float(g["lr"]))
+
+    def _step_scheduler(self) -> None:
+        if self.scheduler is not None:
+            if self._shadow is not None:
+                self._shadow.step()  # keeps torch's "optimizer.step() before lr_scheduler.step()" bookkeeping quiet
+            self.scheduler.step()
+            self._push_lrs()
 
     def forward_loss(self, images: Tensor, targets: List[Any]):
         from sihl_amd import ops  # the HIP library loads lazily: CPU oracle models never need it
@@ -222,6 +267,7 @@ class Trainer:
         self.optimizer.step()
         if self.prepared is not None:
             self.prepared.refresh()
+        self._step_scheduler()
         # detached: a caller holding on to graph-attached metrics would keep this step's autograd graph - and its
         # AccumulateGrad nodes, which remember the stream they were created on - alive into a later graph capture
         return loss.detach(), {k: (v.detach() if isinstance(v, Tensor) else v) for k, v in metrics.items()}
@@ -258,4 +304,5 @@ class Trainer:
         graph, static_leaves, loss, metrics = entry
         torch._foreach_copy_(static_leaves, leaves)
         graph.replay()  # ... the replay does
+        self._step_scheduler()
         return loss, metrics

@@ -53,7 +53,7 @@ def test_graph_step_matches_eager(amp):
     # every element within a few lr-sized steps, and the tensors equal on average to far below one step
     max_tol, mean_tol = (3 * LR, 0.1 * LR) if amp is None else (2e-3, 2e-4)
     for (n, a), b in zip(ref_model.named_parameters(), graph_model.parameters()):
-        d = (a.float() - b.float()).abs()
+        d = (a.detach().float() - b.detach().float()).abs()
         assert float(d.max()) <= max_tol, (n, float(d.max()))
         assert float(d.mean()) <= mean_tol, (n, float(d.mean()))
     tol = 1e-3 if amp is None else 2e-2
@@ -68,3 +68,28 @@ def test_graph_trainer_new_signature_runs_eagerly_then_captures():
         loss, _ = tr.step(*_batch(0, n_boxes))
         assert torch.isfinite(loss)
     assert len(tr._graphs) == 1 and tr._seen[next(iter(tr._graphs))] >= Trainer.GRAPH_WARMUP
+
+
+def test_graph_step_follows_lr_schedule():
+    """In graph mode the learning rates live in device tensors the schedule rewrites before each replay: same
+    values as the eager scheduler, and the replayed AdamW really uses them (lr 0 during the first steps freezes the
+    weights; a later non-zero lr moves them)."""
+    from sihl_amd.train import Trainer
+    sched = torch.optim.lr_scheduler.LambdaLR
+    kw = {"lr_lambda": lambda step: 0.0 if step < 4 else 1.0}
+    ref_model = _model()
+    graph_model = copy.deepcopy(ref_model)
+    eager = Trainer(ref_model, lr=LR, grad_clip_norm=0.1, scheduler=sched, scheduler_kwargs=dict(kw))
+    graphed = Trainer(graph_model, lr=LR, grad_clip_norm=0.1, graph=True, scheduler=sched, scheduler_kwargs=dict(kw))
+    w0 = graph_model.neck.layers[0].up_convs[0][0].weight.detach().clone()
+    for step in range(7):
+        images, targets = _batch(step, (2, 0, 3))
+        eager.step(images, targets)
+        graphed.step(images, targets)
+        for ge, gg in zip(eager.optimizer.param_groups, graphed.optimizer.param_groups):
+            assert abs(float(gg["lr"]) - float(ge["lr"])) <= 1e-12 + 1e-6 * float(ge["lr"]), (step, ge["lr"], gg["lr"])
+        moved = not torch.equal(graph_model.neck.layers[0].up_convs[0][0].weight, w0)
+        # steps 0..3 run with lr 0 (steps 2.. are graph replays): weights must not move until the schedule says so
+        assert moved == (step >= 4), (step, moved)
+    for a, b in zip(ref_model.parameters(), graph_model.parameters()):
+        assert float((a - b).abs().max()) <= 3 * LR

@@ -155,3 +155,27 @@ def test_optimizer_groups_follow_reference():
     assert seen == len(list(model.parameters()))
     fusion = [p for n, p in model.named_parameters() if n.endswith("fusions.0.weights")]
     assert fusion and all(id(p) not in no_decay for p in fusion)
+
+
+def test_trainer_warmup_schedule_matches_reference_recipe():
+    """Trainer(scheduler=..., scheduler_kwargs={"warmup": n}) = LinearLR(0.01 -> 1, n steps) then the scheduler,
+    stepped once per optimisation step (reference lightning_module.py:226-241), on every parameter group."""
+    import oracle
+    from sihl_amd.train import Trainer
+    torch.manual_seed(0)
+    backbone = oracle.ResNetBackbone("resnet18", top_level=5)
+    head = oracle.MulticlassClassification(backbone.out_channels, num_classes=3)
+    model = oracle.SihlModel(backbone, None, [head])
+    tr = Trainer(model, lr=1e-2, backbone_lr_factor=0.1, grad_clip_norm=None,
+                 scheduler=torch.optim.lr_scheduler.StepLR, scheduler_kwargs={"step_size": 2, "gamma": 0.5, "warmup": 3})
+    base = [1e-3 if any(p is q for q in backbone.parameters() for p in g["params"][:1]) else 1e-2
+            for g in tr.optimizer.param_groups]
+    seen = []
+    x, y = torch.rand(2, 3, 32, 32), torch.tensor([0, 2])
+    for _ in range(6):
+        seen.append([g["lr"] for g in tr.optimizer.param_groups])
+        tr.step(x, [y])
+    factors = [0.01, 0.01 + 0.99 / 3, 0.01 + 2 * 0.99 / 3, 1.0, 1.0, 0.5]
+    for lrs, f in zip(seen, factors):
+        for lr, b in zip(lrs, base):
+            assert abs(lr - b * f) < 1e-9 * max(1.0, b), (lrs, f)
