@@ -6,16 +6,28 @@ namespace {
 struct Rec { hipEvent_t a, b; int slot, dtype; double flops, bytes; };
 bool g_on = false;
 std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;  // events are created once and recycled: hipEventCreate per launch cost ~2 ms/step
+size_t g_used = 0;
 std::mutex g_mu;
 Rec g_cur;
 bool g_open = false;
+
+bool take_event(hipEvent_t* e) {
+  if (g_used == g_pool.size()) {
+    hipEvent_t n;
+    if (hipEventCreate(&n) != hipSuccess) return false;
+    g_pool.push_back(n);
+  }
+  *e = g_pool[g_used++];
+  return true;
+}
 }  // namespace
 
 void sihl_prof_begin(int slot, int dtype, double flops, double bytes, hipStream_t stream) {
   if (!g_on) return;
   std::lock_guard<std::mutex> lk(g_mu);
   g_cur.slot = slot; g_cur.dtype = dtype; g_cur.flops = flops; g_cur.bytes = bytes;
-  if (hipEventCreate(&g_cur.a) != hipSuccess || hipEventCreate(&g_cur.b) != hipSuccess) return;
+  if (!take_event(&g_cur.a) || !take_event(&g_cur.b)) return;
   (void)hipEventRecord(g_cur.a, stream);
   g_open = true;
 }
@@ -33,9 +45,9 @@ extern "C" {
 // Turn per-launch event timing on/off; turning it on clears earlier records.
 int sihl_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(g_mu);
-  if (on) {
-    for (auto& r : g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  if (on) {  // earlier records are dropped; their events go back to the pool
     g_recs.clear();
+    g_used = 0;
   }
   g_on = on != 0;
   return 0;
