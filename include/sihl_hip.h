@@ -67,6 +67,19 @@ int sihl_conv2d_fwd(const void* in, const void* wt, const float* bias, void* out
 int sihl_conv2d_dgrad(const void* dout, const void* wt_t, void* din, int N, int H, int W, int Cin, int Cout, int KH,
                       int KW, int stride, int pad, int dil, int dtype, hipStream_t stream);
 
+/* The same two entry points with caller scratch: tiny pyramid levels (<= 64 workgroups of 128 x 64) slice their K loop
+ * over the grid (split-K) when ws_bytes >= sihl_conv2d_ws_bytes(...) of the forward-shaped problem; ws may be NULL. */
+long sihl_conv2d_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil);
+int sihl_conv2d_fwd_ws(const void* in, const void* wt, const float* bias, void* out, int N, int H, int W, int Cin,
+                       int Cout, int KH, int KW, int stride, int pad, int dil, int dtype, int act,
+                       const float* pre_scale, const float* pre_shift, const float* post_scale,
+                       const float* post_shift, int stats_mode, float* stats_ws, long stats_ws_bytes,
+                       long out_image_stride, void* ws, long ws_bytes, hipStream_t stream);
+int sihl_conv2d_dgrad_ws(const void* dout, const void* wt_t, void* din, int N, int H, int W, int Cin, int Cout, int KH,
+                         int KW, int stride, int pad, int dil, int dtype, void* ws, long ws_bytes,
+                         hipStream_t stream);
+int sihl_conv2d_splitk_enable(int on); /* tuning / test hook */
+
 /* Weight gradient (autograd of Conv2d.weight / Linear.weight): dw fp32 [Cout][KH][KW][Cin];
  * accumulate != 0 adds into dw.  Cin, Cout % vector == 0. */
 /* Test hook: bf16 layers with >= 128 channels use an LDS-DMA 256x256-panel kernel; on != 0 forces the

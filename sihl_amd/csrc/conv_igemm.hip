@@ -40,12 +40,16 @@ struct ConvParams {
   int dbg;                // tuning ablation: 1 = no DMA inside the loop, 2 = no MFMA/ds_read (results invalid)
   int in_dilate;          // >1: the input is read as if zero-dilated by this factor (dgrad of a strided conv)
   int gridM, gridN;
+  int splits;       // > 1: split-K - grid.y splits each accumulate a slice of the K stages into `partial`
+  float* partial;   // [splits][M][Cout] fp32 (caller workspace)
+  long partial_bytes;
 };
 
 bool g_force_reg = false;  // test hook: use the register-staged loader
 int g_dbg = 0;
 int g_tile_override = 0;    // test / tuning hook: 0 = heuristic, 128 / 256 = force that pixel-tile size
 int g_nbuf = 0;             // tuning hook: LDS stages of the narrow LDS-DMA tiles (0 = default)
+bool g_splitk = true;       // tuning / test hook: split-K for tiny pyramid levels
 
 constexpr int BM128 = 128;
 constexpr int KCB = 128;         // bytes of K per stage per row
@@ -335,7 +339,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(const Conv
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int ntaps = p.KH * p.KW;
   const int nchunks = (p.Cin + KCE - 1) / KCE;
-  const int nstages = nchunks * ntaps;
+  // split-K (tiny pyramid levels): this workgroup multiplies the stages [s_first, s_first + nstages)
+  const int total_stages = nchunks * ntaps;
+  const int per_split = (total_stages + p.splits - 1) / p.splits;
+  const int s_first = (int)blockIdx.y * per_split;
+  const int nstages = min(total_stages, s_first + per_split) - s_first;
 
   const v4i_t in_rsrc = make_rsrc(p.in, (unsigned)((long)p.N * p.H * p.W * p.Cin * (long)sizeof(T)));
   const v4i_t wt_rsrc = make_rsrc(p.wt, (unsigned)((long)p.Cout * ntaps * p.Cin * (long)sizeof(T)));
@@ -401,7 +409,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(const Conv
   // stages are visited in order (tap fastest, then channel chunk): counters advance by one instead of dividing
   // (two runtime integer divisions per stage were ~0.25 us of dependent VALU latency in a loop whose useful work
   // on a narrow tile is ~0.5 us)
-  int c_kc = 0, c_tap = -1, c_ky = 0, c_kx = -1;
+  int c_kc = s_first / ntaps, c_tap = s_first % ntaps - 1, c_ky = 0, c_kx = -1;  // state "one before s_first"
+  if (c_tap >= 0) { c_ky = c_tap / p.KW; c_kx = c_tap - c_ky * p.KW; }
   auto stage_setup = [&](int /*s*/, int buf) {
     if (++c_tap == ntaps) { c_tap = 0; c_ky = 0; c_kx = 0; ++c_kc; }
     else if (++c_kx == p.KW) { c_kx = 0; ++c_ky; }
@@ -532,7 +541,118 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(const Conv
     nbuf_next = nbuf_next + 1 == NBUF ? 0 : nbuf_next + 1;
   }
   if (p.dbg & 32) return;  // tuning ablation: no epilogue
+  if (p.splits > 1) {  // raw fp32 partial tile; conv_splitk_epilogue_kernel sums the splits and finishes
+    float* part = p.partial + (long)blockIdx.y * p.M * p.Cout;
+    const int half = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int co = n0 + wn * WTN + j * 32 + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (m < p.M && co < p.Cout) part[(long)m * p.Cout + co] = acc[i][j][r];
+        }
+    }
+    return;
+  }
   conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, tile_m, m0, n0);
+}
+
+// Second half of a split-K conv: out = epilogue(sum_s partial[s]) with the same bias / statistics / affine / activation
+// chain as conv_epilogue_body.  Workgroup = one 128-pixel statistics row x 32 output channels.  Dense output only
+// (out_image_stride == Ho*Wo*Cout).
+template <typename T, int ACT, int STATS>
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvParams p) {
+  // thread = (4 consecutive channels, 4 consecutive pixels): all splits x 4 rows of 16-byte loads are in flight at once
+  __shared__ float red[2][32][33];
+  const int c4 = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int co = blockIdx.y * 32 + c4 * 4;
+  const bool cok = co < p.Cout;  // Cout % 4 == 0 (vector width), so the 4 channels are valid together
+  const bool has_pre = p.pre_scale != nullptr, has_post = p.post_scale != nullptr;
+  float bias[4], s1[4], t1[4], s2[4], t2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    bias[e] = (p.bias && cok) ? p.bias[co + e] : 0.f;
+    s1[e] = (has_pre && cok) ? p.pre_scale[co + e] : 1.f;
+    t1[e] = (has_pre && p.pre_shift && cok) ? p.pre_shift[co + e] : 0.f;
+    s2[e] = (has_post && cok) ? p.post_scale[co + e] : 1.f;
+    t2[e] = (has_post && p.post_shift && cok) ? p.post_shift[co + e] : 0.f;
+  }
+  const long slab = (long)p.M * p.Cout;
+  const int mbase = blockIdx.x * 128 + rl * 4;
+  float v[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[k][e] = 0.f;
+  if (cok) {
+    for (int sp = 0; sp < p.splits; ++sp) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (mbase + k < p.M) {
+          const float4 t = *(const float4*)(p.partial + sp * slab + (long)(mbase + k) * p.Cout + co);
+          v[k][0] += t.x; v[k][1] += t.y; v[k][2] += t.z; v[k][3] += t.w;
+        }
+      }
+    }
+  }
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+  T* __restrict__ out = (T*)p.out;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool ok = cok && mbase + k < p.M;
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x = v[k][e] + bias[e];
+      if (STATS == 1 && ok) { ssum[e] += x; ssq[e] += x * x; }
+      x = x * s1[e] + t1[e];
+      if (ACT == SIHL_ACT_RELU) x = fmaxf(x, 0.f);
+      else if (ACT == SIHL_ACT_SILU) x = x / (1.f + expf(-x));
+      else if (ACT == SIHL_ACT_SIGMOID) x = 1.f / (1.f + expf(-x));
+      if (STATS == 2 && ok) { ssum[e] += x; ssq[e] += x * x; }
+      o[e] = x * s2[e] + t2[e];
+    }
+    if (ok) {
+      T* dst = out + (long)(mbase + k) * p.Cout + co;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) elem<T>::st(dst + e, o[e]);
+    }
+  }
+  if (STATS) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][rl][c4 * 4 + e] = ssum[e]; red[1][rl][c4 * 4 + e] = ssq[e]; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int which = threadIdx.x >> 5, col = threadIdx.x & 31;
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) a += red[which][k][col];
+      if (blockIdx.y * 32 + col < p.Cout) p.stats[((long)blockIdx.x * 2 + which) * p.Cout + blockIdx.y * 32 + col] = a;
+    }
+  }
+}
+
+template <typename T>
+void launch_splitk_epilogue(const ConvParams& p, hipStream_t stream) {
+  const dim3 grid((p.M + 127) / 128, (p.Cout + 31) / 32);
+#define SIHL_SKE(A, S) hipLaunchKernelGGL((conv_splitk_epilogue_kernel<T, A, S>), grid, dim3(256), 0, stream, p)
+  if (p.stats_mode == 0) {
+    if (p.act == SIHL_ACT_NONE) SIHL_SKE(SIHL_ACT_NONE, 0);
+    else if (p.act == SIHL_ACT_RELU) SIHL_SKE(SIHL_ACT_RELU, 0);
+    else if (p.act == SIHL_ACT_SILU) SIHL_SKE(SIHL_ACT_SILU, 0);
+    else SIHL_SKE(SIHL_ACT_SIGMOID, 0);
+  } else if (p.stats_mode == 1) {
+    SIHL_SKE(SIHL_ACT_NONE, 1);
+  } else {
+    if (p.act == SIHL_ACT_RELU) SIHL_SKE(SIHL_ACT_RELU, 2);
+    else if (p.act == SIHL_ACT_NONE) SIHL_SKE(SIHL_ACT_NONE, 2);
+    else if (p.act == SIHL_ACT_SILU) SIHL_SKE(SIHL_ACT_SILU, 2);
+    else SIHL_SKE(SIHL_ACT_SIGMOID, 2);
+  }
+#undef SIHL_SKE
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NBUF = 2>
@@ -559,7 +679,8 @@ int launch_dma(const ConvParams& p0, hipStream_t stream) {
   const double flops = 2.0 * p.M * (double)p.Cout * p.KH * p.KW * p.Cin;
   const double bytes = ((double)p.N * p.H * p.W * p.Cin + (double)p.M * p.Cout + (double)p.Cout * p.KH * p.KW * p.Cin) * sizeof(T);
   sihl_prof_begin(SIHL_PROF_CONV, sizeof(T) == 2 ? SIHL_BF16 : SIHL_F32, flops, bytes, stream);
-  hipLaunchKernelGGL(kern, dim3(p.gridM * p.gridN), dim3(WM * WN * 64), LDS, stream, p);
+  hipLaunchKernelGGL(kern, dim3(p.gridM * p.gridN, p.splits), dim3(WM * WN * 64), LDS, stream, p);
+  if (p.splits > 1) launch_splitk_epilogue<T>(p, stream);
   sihl_prof_end(stream);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
@@ -600,8 +721,30 @@ template <typename T, int BN> int stages_for(const ConvParams& p) {
   const long wgs = ((p.M + 127) / 128) * ((p.Cout + BN - 1) / BN);
   return wgs <= 256 ? 4 : 2;
 }
-template <typename T> int launch_n64(const ConvParams& p, hipStream_t stream) {
-  const int nb = stages_for<T, 64>(p);
+// Split-K plan for the 128x64 tile: levels with <= 64 workgroups (2048 pixels x 256 channels and below) walk their
+// whole K loop (36 stages for a 3x3 over 256 channels, ~1 us each) on a fraction of the chip; slicing the stages
+// over grid.y fills it (L7 3x3: 16 workgroups x 36 stages -> 144 x 4) at the price of a small fp32 slab + one
+// finishing kernel.  Returns 1 when not worth it / no workspace.
+template <typename T> int splitk_plan(const ConvParams& p, long ws_bytes) {
+  if (!g_splitk || !p.partial || p.in_dilate > 1) return 1;
+  if (p.out_image_stride != (long)p.Ho * p.Wo * p.Cout) return 1;  // the finishing kernel writes dense rows
+  constexpr int KCE = KCB / (int)sizeof(T);
+  const long wgs = ((p.M + 127) / 128) * ((p.Cout + 63) / 64);
+  const int stages = ((p.Cin + KCE - 1) / KCE) * p.KH * p.KW;
+  if (wgs > 64 || stages < 16) return 1;  // (also tried: <= 256 workgroups with up to 768 slices - no gain on L5/L6)
+  long s = stages / 4;
+  if (s > 256 / wgs) s = 256 / wgs;
+  if (s < 2) return 1;
+  const int per = (int)((stages + s - 1) / s);
+  s = (stages + per - 1) / per;  // every split non-empty
+  if (s < 2 || ws_bytes < s * (long)p.M * p.Cout * (long)sizeof(float)) return 1;
+  return (int)s;
+}
+
+template <typename T> int launch_n64(const ConvParams& p0, hipStream_t stream) {
+  ConvParams p = p0;
+  p.splits = splitk_plan<T>(p0, p0.partial_bytes);
+  const int nb = p.splits > 1 ? 4 : stages_for<T, 64>(p);
   if (nb == 2) return launch_dma<T, 128, 64, 4, 1, 2>(p, stream);
   if (nb == 3) return launch_dma<T, 128, 64, 4, 1, 3>(p, stream);
   return launch_dma<T, 128, 64, 4, 1, 4>(p, stream);
@@ -653,6 +796,15 @@ int dispatch(const ConvParams& p, hipStream_t stream) {
 
 extern "C" {
 
+int sihl_conv2d_fwd_ws(const void* in, const void* wt, const float* bias, void* out, int N, int H, int W, int Cin,
+                       int Cout, int KH, int KW, int stride, int pad, int dil, int dtype, int act,
+                       const float* pre_scale, const float* pre_shift, const float* post_scale,
+                       const float* post_shift, int stats_mode, float* stats_ws, long stats_ws_bytes,
+                       long out_image_stride, void* ws, long ws_bytes, hipStream_t stream);
+int sihl_conv2d_dgrad_ws(const void* dout, const void* wt_t, void* din, int N, int H, int W, int Cin, int Cout, int KH,
+                         int KW, int stride, int pad, int dil, int dtype, void* ws, long ws_bytes,
+                         hipStream_t stream);
+
 // Test hook: 1 = use the register-staged loader instead of LDS-DMA (both are kept parity-tested).
 int sihl_conv2d_force_register_staging(int on) { g_force_reg = on != 0; return 0; }
 
@@ -668,11 +820,34 @@ int sihl_conv2d_tile_override(int bm) { g_tile_override = bm; return 0; }
 // Number of (sum, sumsq) partial rows the conv may write for M output pixels (upper bound over tile sizes).
 int sihl_conv2d_stat_rows(long M) { return (int)((M + BM128 - 1) / BM128); }
 
+// fp32 scratch a conv launch may use (split-K of tiny pyramid levels); 0 when the shape never splits.
+long sihl_conv2d_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil) {
+  const int Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return 0;
+  const long M = (long)N * Ho * Wo;
+  if (((M + 127) / 128) * ((Cout + 63) / 64) > 64) return 0;
+  return 9L * M * Cout * (long)sizeof(float);
+}
+
+// Tuning / test hook: 0 disables split-K.
+int sihl_conv2d_splitk_enable(int on) { g_splitk = on != 0; return 0; }
+
 int sihl_conv2d_fwd(const void* in, const void* wt, const float* bias, void* out, int N, int H, int W, int Cin,
                     int Cout, int KH, int KW, int stride, int pad, int dil, int dtype, int act,
                     const float* pre_scale, const float* pre_shift, const float* post_scale,
                     const float* post_shift, int stats_mode, float* stats_ws, long stats_ws_bytes,
                     long out_image_stride, hipStream_t stream) {
+  return sihl_conv2d_fwd_ws(in, wt, bias, out, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, dtype, act, pre_scale,
+                            pre_shift, post_scale, post_shift, stats_mode, stats_ws, stats_ws_bytes, out_image_stride,
+                            nullptr, 0, stream);
+}
+
+// sihl_conv2d_fwd with caller scratch (ws_bytes >= sihl_conv2d_ws_bytes(...) enables split-K; ws may be NULL).
+int sihl_conv2d_fwd_ws(const void* in, const void* wt, const float* bias, void* out, int N, int H, int W, int Cin,
+                       int Cout, int KH, int KW, int stride, int pad, int dil, int dtype, int act,
+                       const float* pre_scale, const float* pre_shift, const float* post_scale,
+                       const float* post_shift, int stats_mode, float* stats_ws, long stats_ws_bytes,
+                       long out_image_stride, void* ws, long ws_bytes, hipStream_t stream) {
   if (!in || !wt || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 ||
       stride <= 0 || dil <= 0 || pad < 0)
     return SIHL_EARG;
@@ -700,6 +875,7 @@ int sihl_conv2d_fwd(const void* in, const void* wt, const float* bias, void* out
     if (!stats_ws) return SIHL_EARG;
     if (stats_ws_bytes < (long)sihl_conv2d_stat_rows(M) * 2 * Cout * (long)sizeof(float)) return SIHL_EWS;
   }
+  p.splits = 1; p.partial = (float*)ws; p.partial_bytes = ws ? ws_bytes : 0;
   if (dtype == SIHL_F32) return dispatch<float>(p, stream);
   if (dtype == SIHL_BF16) return dispatch<bf16_t>(p, stream);
   return SIHL_EARG;
@@ -709,6 +885,14 @@ int sihl_conv2d_fwd(const void* in, const void* wt, const float* bias, void* out
 // wt_t = sihl_weight_flip_transpose(w, flip=1) is [Cin][KH][KW][Cout].  dout is read as if zero-dilated by `stride`.
 int sihl_conv2d_dgrad(const void* dout, const void* wt_t, void* din, int N, int H, int W, int Cin, int Cout, int KH,
                       int KW, int stride, int pad, int dil, int dtype, hipStream_t stream) {
+  return sihl_conv2d_dgrad_ws(dout, wt_t, din, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, dtype, nullptr, 0, stream);
+}
+
+// sihl_conv2d_dgrad with caller scratch: ws_bytes >= sihl_conv2d_ws_bytes(N, Ho, Wo, Cout, Cin, KH, KW, 1, ...) of
+// the equivalent forward problem (output = din) enables split-K.
+int sihl_conv2d_dgrad_ws(const void* dout, const void* wt_t, void* din, int N, int H, int W, int Cin, int Cout, int KH,
+                         int KW, int stride, int pad, int dil, int dtype, void* ws, long ws_bytes,
+                         hipStream_t stream) {
   if (!dout || !wt_t || !din || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 ||
       stride <= 0 || dil <= 0 || pad < 0)
     return SIHL_EARG;
@@ -733,6 +917,7 @@ int sihl_conv2d_dgrad(const void* dout, const void* wt_t, void* din, int N, int 
   p.in_dilate = stride;
   p.dbg = 0;
   p.out_image_stride = (long)H * W * Cin;
+  p.splits = 1; p.partial = (float*)ws; p.partial_bytes = ws ? ws_bytes : 0;
   if (dtype == SIHL_F32) return dispatch<float>(p, stream);
   if (dtype == SIHL_BF16) return dispatch<bf16_t>(p, stream);
   return SIHL_EARG;

@@ -210,12 +210,15 @@ def conv2d_raw(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, stride: int 
         rows = _C.lib().sihl_conv2d_stat_rows(N * Ho * Wo)
         stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
         stats_bytes = stats.numel() * 4
-    rc = _C.lib().sihl_conv2d_fwd(
+    lib = _C.lib()
+    ws_bytes = lib.sihl_conv2d_ws_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad, dil)  # > 0: tiny level, split-K
+    ws = workspace(ws_bytes, x.device) if ws_bytes else None
+    rc = lib.sihl_conv2d_fwd_ws(
         _p(x), _p(w), _p(bias), _p(out), N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x), ACT[act],
         _p(pre[0]) if pre else None, _p(pre[1]) if pre else None,
         _p(post[0]) if post else None, _p(post[1]) if post else None,
-        stats_mode, _p(stats), stats_bytes, out_image_stride, _stream())
-    check(rc, "sihl_conv2d_fwd")
+        stats_mode, _p(stats), stats_bytes, out_image_stride, _p(ws), ws.numel() if ws is not None else 0, _stream())
+    check(rc, "sihl_conv2d_fwd_ws")
     return out, stats
 
 
@@ -403,8 +406,12 @@ class ConvBlockFn(torch.autograd.Function):
             wt = ctx.wt if ctx.wt is not None else weight_for_dgrad(w, flip=True)
             dx = torch.empty_like(x)
             N, H, W, Cin = x.shape
-            rc = _C.lib().sihl_conv2d_dgrad(_p(dz), _p(wt), _p(dx), N, H, W, Cin, w.shape[0], KH, KW, stride, pad,
-                                            dil, _dt(x), _stream())
+            lib = _C.lib()
+            ws_bytes = lib.sihl_conv2d_ws_bytes(N, H, W, w.shape[0], Cin, KH, KW, 1, dil * (KH - 1) - pad, dil) \
+                if stride == 1 else 0
+            ws = workspace(ws_bytes, x.device) if ws_bytes else None
+            rc = lib.sihl_conv2d_dgrad_ws(_p(dz), _p(wt), _p(dx), N, H, W, Cin, w.shape[0], KH, KW, stride, pad,
+                                          dil, _dt(x), _p(ws), ws.numel() if ws is not None else 0, _stream())
             check(rc, "sihl_conv2d_dgrad")
         return dx, dw, dbias, dgamma, dbeta, None, None, None, dres
 

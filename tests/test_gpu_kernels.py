@@ -272,3 +272,33 @@ def test_iseg_mask_decode_matches_torch(dtype, tol, B, K, h, w, H, W):
     x = (torch.einsum("nchw,ncd->ndhw", x, w3) + b3).sigmoid()
     want = F.interpolate(x.reshape(B, K, h, w), size=(H, W), mode="bilinear")
     torch.testing.assert_close(got.float(), want, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 0.0)])
+@pytest.mark.parametrize("shape", [(2, 4, 4, 256, 256, 3), (3, 8, 8, 256, 256, 3), (2, 4, 4, 2048, 256, 1), (1, 5, 7, 72, 40, 3)])
+def test_conv_splitk_matches_single_pass(shape, dtype, tol):
+    """Tiny levels run split-K (K stages sliced over grid.y + a finishing kernel): outputs and BatchNorm partial sums
+    must equal the single-pass kernel (bf16: bit-identical outputs are not guaranteed - fp32 partial sums are added in
+    a different order - so both are compared with the fp32 reference)."""
+    from sihl_amd import _C, ops
+    N, H, W, Cin, Cout, K = shape
+    torch.manual_seed(5)
+    x = torch.randn(N, H, W, Cin, device="cuda").to(dtype)
+    w = (torch.randn(Cout, K, K, Cin, device="cuda") * 0.05).to(dtype)
+    bias = torch.randn(Cout, device="cuda")
+    lib = _C.lib()
+    outs = {}
+    for on in (0, 1):
+        lib.sihl_conv2d_splitk_enable(on)
+        try:
+            outs[on] = ops.conv2d_raw(x, w, bias, 1, K // 2, 1, act="relu", stats_mode=2)
+        finally:
+            lib.sihl_conv2d_splitk_enable(1)
+    ref = torch.relu(torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias,
+                                                padding=K // 2)).permute(0, 2, 3, 1)
+    rtol = 1e-4 if dtype == torch.float32 else 2e-2
+    for on in (0, 1):
+        y, stats = outs[on]
+        torch.testing.assert_close(y.float(), ref, rtol=rtol, atol=rtol * float(ref.abs().max()))
+        torch.testing.assert_close(stats[:, 0].sum(0), ref.reshape(-1, Cout).sum(0), rtol=rtol, atol=rtol * float(ref.abs().sum(0).max()))
+    torch.testing.assert_close(outs[1][1].sum(0), outs[0][1].sum(0), rtol=1e-3, atol=1e-3 * float(outs[0][1].abs().max()))
