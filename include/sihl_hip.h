@@ -99,9 +99,11 @@ int sihl_weight_flip_transpose(const void* w, void* o, int Cout, int KH, int KW,
 /* All weights of a model in one launch: fp32 master [O][I][KH][KW] (any strides) -> bf16 w [Op][KH][KW][I] and
  * bf16 wt [I][KH][KW][Op] (flipped when flip != 0), Op = O padded to the vector width with zero rows.  descs is a
  * DEVICE array of n records {const float* src; bf16* w; bf16* wt; int64 so, si, sky, skx; int32 O, Op, KH, KW, I,
- * flip; int64 first_block} (88 bytes); a record owns blocks [first_block, first_block + ceil(Op*KH*KW*I/2048)).
+ * flip; int64 first_block, first_tblock} (96 bytes); a record owns blocks [first_block, first_block +
+ * ceil(Op*KH*KW*I/2048)) of the w pass and tiles [first_tblock, first_tblock + KH*KW*ceil(Op/64)*ceil(I/64)) of the
+ * transposing wt pass.
  * Replaces the per-layer .to(bf16) + sihl_weight_flip_transpose the autocast path of the reference implies. */
-int sihl_weight_prepare(const void* descs, int n, long total_blocks, hipStream_t stream);
+int sihl_weight_prepare(const void* descs, int n, long total_blocks, long total_tblocks, hipStream_t stream);
 
 /* ---- BatchNorm2d (convblocks.py:82-85; torch defaults eps 1e-5, momentum 0.1) ------------------------------
  * finalize: partial sums -> batch mean / rstd (biased variance), scale = gamma*rstd, shift = beta - mean*scale,

@@ -33,7 +33,7 @@ SIGNATURES = {
     "sihl_conv2d_wgrad_ws_bytes": (L, [I, I, I, I, I, I, I, I, I, I, I]),
     "sihl_conv2d_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, L, P]),
     "sihl_weight_flip_transpose": (I, [P, P, I, I, I, I, I, I, I, P]),
-    "sihl_weight_prepare": (I, [P, I, L, P]),
+    "sihl_weight_prepare": (I, [P, I, L, L, P]),
     "sihl_bn_finalize": (I, [P, I, I, L, P, P, F, F, P, P, P, P, P, P, P]),
     "sihl_bn_eval_affine": (I, [P, P, P, P, F, I, P, P, P]),
     "sihl_affine_act": (I, [P, P, L, I, P, P, I, I, P]),

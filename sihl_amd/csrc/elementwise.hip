@@ -1104,52 +1104,73 @@ struct WeightDesc {
   const float* src; bf16_t* w; bf16_t* wt;
   long so, si, sky, skx;  // source element strides
   int O, Op, KH, KW, I, flip;
-  long first_block;
+  long first_block;   // w copy: blocks of 2048 destination elements
+  long first_tblock;  // wt copy: 64 o x 64 i tiles per tap
 };
 
-__global__ void weight_prepare_kernel(const WeightDesc* __restrict__ descs, int n) {
-  int lo = 0, hi = n - 1;  // last descriptor whose first_block <= blockIdx.x
+__device__ __forceinline__ const WeightDesc* find_desc(const WeightDesc* descs, int n, long block, bool tiles) {
+  int lo = 0, hi = n - 1;  // last descriptor whose first block <= block
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (descs[mid].first_block <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+    if ((tiles ? descs[mid].first_tblock : descs[mid].first_block) <= block) lo = mid; else hi = mid - 1;
   }
-  const WeightDesc d = descs[lo];
+  return descs + lo;
+}
+
+// w [Op][KH][KW][I]: same element order as a channels-last master weight, so reads and writes are both contiguous
+__global__ void weight_prepare_kernel(const WeightDesc* __restrict__ descs, int n) {
+  const WeightDesc d = *find_desc(descs, n, blockIdx.x, false);
   const long total = (long)d.Op * d.KH * d.KW * d.I;
   const long e0 = ((long)blockIdx.x - d.first_block) * 2048 + threadIdx.x * 8;
   if (e0 >= total) return;
   const int cnt = (int)min(8L, total - e0);
-  // ---- w: index (o, ky, kx, i), i fastest
-  {
-    long t = e0;
-    int i = (int)(t % d.I); t /= d.I;
-    int kx = (int)(t % d.KW); t /= d.KW;
-    int ky = (int)(t % d.KH);
-    int o = (int)(t / d.KH);
-    float f[8];
+  long t = e0;
+  int i = (int)(t % d.I); t /= d.I;
+  int kx = (int)(t % d.KW); t /= d.KW;
+  int ky = (int)(t % d.KH);
+  int o = (int)(t / d.KH);
+  float f[8];
+  const float* row = d.src + o * d.so + i * d.si + ky * d.sky + kx * d.skx;
+  if (d.si == 1 && (d.I & 7) == 0 && cnt == 8 && (((unsigned long)row) & 15) == 0) {
+    // channels-last master weight: the 8 destination elements are 8 consecutive source floats
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+    if (o < d.O) { a = *(const float4*)row; c = *(const float4*)(row + 4); }
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = c.x; f[5] = c.y; f[6] = c.z; f[7] = c.w;
+  } else {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       f[k] = (k < cnt && o < d.O) ? d.src[o * d.so + i * d.si + ky * d.sky + kx * d.skx] : 0.f;
       if (++i == d.I) { i = 0; if (++kx == d.KW) { kx = 0; if (++ky == d.KH) { ky = 0; ++o; } } }
     }
-    if (cnt == 8) *(uint4*)(d.w + e0) = pack16(f, bf16_t());
-    else for (int k = 0; k < cnt; ++k) elem<bf16_t>::st(d.w + e0 + k, f[k]);
   }
-  // ---- wt: index (i, ky, kx, o), o fastest; source tap mirrored when flip
-  {
-    long t = e0;
-    int o = (int)(t % d.Op); t /= d.Op;
-    int kx = (int)(t % d.KW); t /= d.KW;
-    int ky = (int)(t % d.KH);
-    int i = (int)(t / d.KH);
-    float f[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int sy = d.flip ? d.KH - 1 - ky : ky, sx = d.flip ? d.KW - 1 - kx : kx;
-      f[k] = (k < cnt && o < d.O) ? d.src[o * d.so + i * d.si + sy * d.sky + sx * d.skx] : 0.f;
-      if (++o == d.Op) { o = 0; if (++kx == d.KW) { kx = 0; if (++ky == d.KH) { ky = 0; ++i; } } }
-    }
-    if (cnt == 8) *(uint4*)(d.wt + e0) = pack16(f, bf16_t());
-    else for (int k = 0; k < cnt; ++k) elem<bf16_t>::st(d.wt + e0 + k, f[k]);
+  if (cnt == 8) *(uint4*)(d.w + e0) = pack16(f, bf16_t());
+  else for (int k = 0; k < cnt; ++k) elem<bf16_t>::st(d.w + e0 + k, f[k]);
+}
+
+// wt [I][KH][KW][Op] (tap mirrored when flip): a 64 o x 64 i tile of one tap goes through LDS so that the master
+// weight is read along i (its contiguous axis when channels-last) and the copy is written along o.  (Gathering the
+// source per destination element fetched 11x the bytes: 2.2 GB for 193 MB of weights.)
+__global__ void weight_prepare_t_kernel(const WeightDesc* __restrict__ descs, int n) {
+  __shared__ float tile[64][65];
+  const WeightDesc d = *find_desc(descs, n, blockIdx.x, true);
+  long b = (long)blockIdx.x - d.first_tblock;
+  const int tiles_i = (d.I + 63) / 64, tiles_o = (d.Op + 63) / 64;
+  const int ti = (int)(b % tiles_i); b /= tiles_i;
+  const int to = (int)(b % tiles_o); b /= tiles_o;
+  const int tap = (int)b, ky = tap / d.KW, kx = tap - ky * d.KW;
+  const int sy = d.flip ? d.KH - 1 - ky : ky, sx = d.flip ? d.KW - 1 - kx : kx;
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;  // 256 threads: 64 columns x 4 rows per pass
+  const int i_in = ti * 64 + lx;
+  for (int r = ly; r < 64; r += 4) {
+    const int o = to * 64 + r;
+    tile[r][lx] = (o < d.O && i_in < d.I) ? d.src[o * d.so + i_in * d.si + sy * d.sky + sx * d.skx] : 0.f;
+  }
+  __syncthreads();
+  const int o_out = to * 64 + lx;
+  for (int r = ly; r < 64; r += 4) {
+    const int i = ti * 64 + r;
+    if (i < d.I && o_out < d.Op)
+      elem<bf16_t>::st(d.wt + (((long)i * d.KH + ky) * d.KW + kx) * d.Op + o_out, tile[lx][r]);
   }
 }
 
@@ -1569,12 +1590,17 @@ int sihl_weight_flip_transpose(const void* w, void* o, int Cout, int KH, int KW,
   return SIHL_OK;
 }
 
-// descs: DEVICE array of n sihl weight descriptors (layout of struct WeightDesc above, 88 bytes each; built once by
-// the host mirror), total_blocks = sum over weights of ceil(Op*KH*KW*I / 2048).
-int sihl_weight_prepare(const void* descs, int n, long total_blocks, hipStream_t stream) {
-  if (!descs || n <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffL) return SIHL_EARG;
-  static_assert(sizeof(WeightDesc) == 88, "descriptor layout is part of the C-ABI");
+// descs: DEVICE array of n sihl weight descriptors (layout of struct WeightDesc above, 96 bytes each; built once by
+// the host mirror), total_blocks = sum over weights of ceil(Op*KH*KW*I / 2048), total_tblocks = sum of
+// KH*KW*ceil(Op/64)*ceil(I/64).
+int sihl_weight_prepare(const void* descs, int n, long total_blocks, long total_tblocks, hipStream_t stream) {
+  if (!descs || n <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffL || total_tblocks <= 0 ||
+      total_tblocks > 0x7fffffffL)
+    return SIHL_EARG;
+  static_assert(sizeof(WeightDesc) == 96, "descriptor layout is part of the C-ABI");
   hipLaunchKernelGGL(weight_prepare_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream,
+                     (const WeightDesc*)descs, n);
+  hipLaunchKernelGGL(weight_prepare_t_kernel, dim3((unsigned)total_tblocks), dim3(256), 0, stream,
                      (const WeightDesc*)descs, n);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;

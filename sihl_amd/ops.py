@@ -119,7 +119,8 @@ class _WeightDesc(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("w", ctypes.c_void_p), ("wt", ctypes.c_void_p),
                 ("so", ctypes.c_int64), ("si", ctypes.c_int64), ("sky", ctypes.c_int64), ("skx", ctypes.c_int64),
                 ("O", ctypes.c_int32), ("Op", ctypes.c_int32), ("KH", ctypes.c_int32), ("KW", ctypes.c_int32),
-                ("I", ctypes.c_int32), ("flip", ctypes.c_int32), ("first_block", ctypes.c_int64)]
+                ("I", ctypes.c_int32), ("flip", ctypes.c_int32), ("first_block", ctypes.c_int64),
+                ("first_tblock", ctypes.c_int64)]
 
 
 class PreparedWeights:
@@ -156,7 +157,7 @@ class PreparedWeights:
         dev = weights[0].device
         self._flat = torch.zeros(2 * total + 16, dtype=dtype, device=dev)
         descs = (_WeightDesc * len(weights))()
-        off, block = 0, 0
+        off, block, tblock = 0, 0, 0
         for k, (p, (O, Op, KH, KW, I)) in enumerate(zip(weights, geo)):
             n = Op * KH * KW * I
             w = self._flat[off: off + n].view(Op, KH, KW, I)
@@ -172,9 +173,10 @@ class PreparedWeights:
             d.sky, d.skx = (st[2], st[3]) if p.dim() == 4 else (0, 0)
             d.O, d.Op, d.KH, d.KW, d.I = O, Op, KH, KW, I
             d.flip = 1 if p.dim() == 4 else 0
-            d.first_block = block
+            d.first_block, d.first_tblock = block, tblock
             block += (n + 2047) // 2048
-        self._blocks = block
+            tblock += KH * KW * ((Op + 63) // 64) * ((I + 63) // 64)
+        self._blocks, self._tblocks = block, tblock
         raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)
         self._table = raw.to(dev)
         self._ptrs = [p.data_ptr() for p in weights]
@@ -185,7 +187,7 @@ class PreparedWeights:
             return
         if [p.data_ptr() for p in self.weights] != self._ptrs:
             raise RuntimeError("a prepared weight was re-allocated; build a new PreparedWeights")
-        rc = _C.lib().sihl_weight_prepare(_p(self._table), len(self.weights), self._blocks, _stream())
+        rc = _C.lib().sihl_weight_prepare(_p(self._table), len(self.weights), self._blocks, self._tblocks, _stream())
         check(rc, "sihl_weight_prepare")
         for p in self.weights:
             p._sihl_prepared.version = p._version
