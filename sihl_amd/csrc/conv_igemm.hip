@@ -327,7 +327,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(const Conv
   constexpr int NKS = KCB / 32;                                    // k-steps per stage
   constexpr int PER_STAGE = NA + NBL;                              // DMA instructions per thread per stage
   static_assert(NA >= 1 && NBL >= 1, "tile too small for the thread count");
-  static_assert(NBUF >= 2 && NBUF <= 4 && (NBUF - 2) * PER_STAGE <= 63, "vmcnt immediate range");
+  static_assert(NBUF >= 1 && NBUF <= 4 && (NBUF < 2 || (NBUF - 2) * PER_STAGE <= 63), "vmcnt immediate range");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -458,6 +458,35 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(const Conv
     else if (NBUF >= 3 && keep >= 1) wait_vm_keep<PER_STAGE>();
     else wait_vm_keep<0>();
   };
+  if constexpr (NBUF == 1) {
+    // One LDS stage: load -> multiply -> load ...  No overlap inside the workgroup; the small footprint lets two or
+    // three workgroups share a CU and overlap each other (thin-K pointwise layers: one or two stages in total, where
+    // the output store of one workgroup runs under the loads of the next).
+    const char* As = smem + wm * WTM * KCB;
+    const char* Bs = smem + A_BYTES + wn * WTN * KCB;
+    for (int s = 0; s < nstages; ++s) {
+      stage_setup(s, 0);
+#pragma unroll
+      for (int j = 0; j < NA; ++j) issue_a(j);
+#pragma unroll
+      for (int j = 0; j < NBL; ++j) issue_b(j);
+      wait_vm_keep<0>();
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        uint4 fa[MT], fb[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[i] = *(const uint4*)(As + i * 32 * KCB + koff[ks]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[j] = *(const uint4*)(Bs + j * 32 * KCB + koff[ks]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) mma_step<T>(acc[i][j], fa[i], fb[j]);
+      }
+      __syncthreads();  // everyone is done with the stage before it is overwritten (or reused by the epilogue)
+    }
+  } else {
 #pragma unroll
   for (int s0 = 0; s0 < NBUF - 1; ++s0) {
     if (s0 < nstages) {
@@ -540,6 +569,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(const Conv
     buf = buf + 1 == NBUF ? 0 : buf + 1;
     nbuf_next = nbuf_next + 1 == NBUF ? 0 : nbuf_next + 1;
   }
+  }  // NBUF > 1
   if (p.dbg & 32) return;  // tuning ablation: no epilogue
   if (p.splits > 1) {  // raw fp32 partial tile; conv_splitk_epilogue_kernel sums the splits and finishes
     float* part = p.partial + (long)blockIdx.y * p.M * p.Cout;
@@ -712,14 +742,20 @@ int launch_reg(const ConvParams& p0, hipStream_t stream) {
 }
 
 // stage-count selection of the narrow tiles (g_nbuf: tuning hook, 0 = default)
-// Two stages keep the LDS footprint at <= 64 KB, so two workgroups share a CU and hide each other's waits - worth
+// Few LDS stages keep the footprint small, so several workgroups share a CU and hide each other's waits - worth
 // more than a deeper pipeline whenever the grid has more workgroups than CUs (measured: L4 3x3 60 us with 2 stages,
 // 93 us with 4).  Grids of <= 256 workgroups are alone on their CU anyway and take 4 stages (lat5 1x1 K=2048:
 // 42 -> 32 us).
 template <typename T, int BN> int stages_for(const ConvParams& p) {
   if (g_nbuf) return g_nbuf;
   const long wgs = ((p.M + 127) / 128) * ((p.Cout + BN - 1) / BN);
-  return wgs <= 256 ? 4 : 2;
+  if (wgs <= 256) return 4;
+  // Bigger grids: ONE stage (32-48 KB of LDS with the epilogue staging: 3-4 workgroups per CU hide each other's
+  // load -> multiply -> store phases) beats two stages for windowed convs and thin-K pointwise layers - r1 3x3 64:
+  // 120 -> 88 us, r3 1x1 256>1024: 49 -> 39, L4 3x3: 62 -> 57 - but not for pointwise layers with a long K loop
+  // into few channels (r2 1x1 512>128: 46 -> 50, r3 1x1 1024>256: 34 -> 36), which keep two.
+  if (p.KH * p.KW > 1 || p.Cin <= 256 || p.Cout >= 1024) return 1;
+  return 2;
 }
 // Split-K plan for the 128x64 tile: levels with <= 64 workgroups (2048 pixels x 256 channels and below) walk their
 // whole K loop (36 stages for a 3x3 over 256 channels, ~1 us each) on a fraction of the chip; slicing the stages
@@ -745,12 +781,14 @@ template <typename T> int launch_n64(const ConvParams& p0, hipStream_t stream) {
   ConvParams p = p0;
   p.splits = splitk_plan<T>(p0, p0.partial_bytes);
   const int nb = p.splits > 1 ? 4 : stages_for<T, 64>(p);
+  if (nb == 1) return launch_dma<T, 128, 64, 4, 1, 1>(p, stream);
   if (nb == 2) return launch_dma<T, 128, 64, 4, 1, 2>(p, stream);
   if (nb == 3) return launch_dma<T, 128, 64, 4, 1, 3>(p, stream);
   return launch_dma<T, 128, 64, 4, 1, 4>(p, stream);
 }
 template <typename T> int launch_n128(const ConvParams& p, hipStream_t stream) {
   const int nb = stages_for<T, 128>(p);
+  if (nb == 1) return launch_dma<T, 128, 128, 2, 2, 1>(p, stream);
   if (nb == 2) return launch_dma<T, 128, 128, 2, 2, 2>(p, stream);
   if (nb == 3) return launch_dma<T, 128, 128, 2, 2, 3>(p, stream);
   return launch_dma<T, 128, 128, 2, 2, 4>(p, stream);
