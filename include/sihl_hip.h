@@ -79,6 +79,7 @@ int sihl_conv2d_dgrad_ws(const void* dout, const void* wt_t, void* din, int N, i
                          int KW, int stride, int pad, int dil, int dtype, void* ws, long ws_bytes,
                          hipStream_t stream);
 int sihl_conv2d_splitk_enable(int on); /* tuning / test hook */
+int sihl_conv2d_rules_off(int mask);   /* tuning hook: disable individual dispatch rules */
 
 /* Weight gradient (autograd of Conv2d.weight / Linear.weight): dw fp32 [Cout][KH][KW][Cin];
  * accumulate != 0 adds into dw.  Cin, Cout % vector == 0. */

@@ -50,6 +50,7 @@ int g_dbg = 0;
 int g_tile_override = 0;    // test / tuning hook: 0 = heuristic, 128 / 256 = force that pixel-tile size
 int g_nbuf = 0;             // tuning hook: LDS stages of the narrow LDS-DMA tiles (0 = default)
 bool g_splitk = true;       // tuning / test hook: split-K for tiny pyramid levels
+int g_rules_off = 0;        // tuning hook: bit 0 = no single-stage narrow tiles, bit 1 = no 128x128 routing of thin pointwise layers
 
 constexpr int BM128 = 128;
 constexpr int KCB = 128;         // bytes of K per stage per row
@@ -754,7 +755,7 @@ template <typename T, int BN> int stages_for(const ConvParams& p) {
   // load -> multiply -> store phases) beats two stages for windowed convs and thin-K pointwise layers - r1 3x3 64:
   // 120 -> 88 us, r3 1x1 256>1024: 49 -> 39, L4 3x3: 62 -> 57 - but not for pointwise layers with a long K loop
   // into few channels (r2 1x1 512>128: 46 -> 50, r3 1x1 1024>256: 34 -> 36), which keep two.
-  if (p.KH * p.KW > 1 || p.Cin <= 256 || p.Cout >= 1024) return 1;
+  if (!(g_rules_off & 1) && (p.KH * p.KW > 1 || p.Cin <= 256 || p.Cout >= 1024)) return 1;
   return 2;
 }
 // Split-K plan for the 128x64 tile: levels with <= 64 workgroups (2048 pixels x 256 channels and below) walk their
@@ -812,6 +813,11 @@ int dispatch(const ConvParams& p, hipStream_t stream) {
     // on a handful of workgroups): narrower channel tiles spread them over 2-4x more CUs.
     const long tiles128 = (p.M + 127) / 128;
     if constexpr (sizeof(T) == 2) {
+      // pointwise, K <= 256 into <= 256 channels (ResNet layer1 expansions, the MLP linears): two channel tiles of
+      // 128x128, single stage, 4 workgroups per CU - r1 64>256: 114 -> 104 us, mlp 65 -> 60; wider outputs or a
+      // window lose (r2 128>512: 63 -> 66, L3 3x3: 156 -> 182)
+      if (g_tile_override == 0 && !(g_rules_off & 2) && p.M >= 256 * 256 && p.KH * p.KW == 1 && p.Cin <= 256 && p.Cout <= 256)
+        return launch_n128<T>(p, stream);
       if (g_tile_override == 256 || (g_tile_override == 0 && p.M >= 256 * 256))
         return launch_dma<T, 256, 256, 4, 2>(p, stream);
     }
@@ -866,6 +872,9 @@ long sihl_conv2d_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW
   if (((M + 127) / 128) * ((Cout + 63) / 64) > 64) return 0;
   return 9L * M * Cout * (long)sizeof(float);
 }
+
+// Tuning hook: switch individual dispatch rules off (bit 0: single-stage narrow tiles, bit 1: thin pointwise -> 128x128).
+int sihl_conv2d_rules_off(int mask) { g_rules_off = mask; return 0; }
 
 // Tuning / test hook: 0 disables split-K.
 int sihl_conv2d_splitk_enable(int on) { g_splitk = on != 0; return 0; }
