@@ -75,8 +75,9 @@ int sihl_conv2d_fwd_ws(const void* in, const void* wt, const float* bias, void* 
                        const float* pre_scale, const float* pre_shift, const float* post_scale,
                        const float* post_shift, int stats_mode, float* stats_ws, long stats_ws_bytes,
                        long out_image_stride, void* ws, long ws_bytes, hipStream_t stream);
-int sihl_conv2d_dgrad_ws(const void* dout, const void* wt_t, void* din, int N, int H, int W, int Cin, int Cout, int KH,
-                         int KW, int stride, int pad, int dil, int dtype, void* ws, long ws_bytes,
+/* add: optional dense [N][H][W][Cin] tensor added to the result (identity-branch gradient of a residual block) */
+int sihl_conv2d_dgrad_ws(const void* dout, const void* wt_t, void* din, const void* add, int N, int H, int W, int Cin,
+                         int Cout, int KH, int KW, int stride, int pad, int dil, int dtype, void* ws, long ws_bytes,
                          hipStream_t stream);
 int sihl_conv2d_splitk_enable(int on); /* tuning / test hook */
 int sihl_conv2d_rules_off(int mask);   /* tuning hook: disable individual dispatch rules */

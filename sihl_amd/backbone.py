@@ -23,14 +23,24 @@ from sihl_amd import ops
 from sihl_amd.layers.scalers import AntialiasedDownscaler
 
 
-def _conv_bn(x: Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, act, training: bool, residual=None) -> Tensor:
+def _conv_bn(x: Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, act, training: bool, residual=None, hand_over=None,
+             take_over=None) -> Tensor:
     """conv -> BatchNorm -> act on NHWC tensors through the fused HIP conv block (torchvision order); with
     ``residual`` the block tail relu(BN(conv(x)) + residual) is one normalise+add+ReLU pass."""
     if training:
         ops.bump_counter(bn.num_batches_tracked)
     return ops.conv_block(x, conv.weight, None, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                           stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0], act=act,
-                          order="norm_act", training=training, eps=bn.eps, momentum=bn.momentum, residual=residual)
+                          order="norm_act", training=training, eps=bn.eps, momentum=bn.momentum, residual=residual,
+                          hand_over=hand_over, take_over=take_over)
+
+
+def _carrier(block, x: Tensor, training: bool):
+    """A GradCarrier for identity blocks in training: the shortcut's gradient then rides on conv1's dgrad.  Needs the
+    first conv to produce an input gradient of x's shape (stride 1, x requires grad, conv1 trainable path)."""
+    ok = (training and block.downsample is None and torch.is_grad_enabled() and x.requires_grad
+          and block.conv1.stride[0] == 1 and not __import__("os").environ.get("SIHL_NO_GRAD_CARRIER"))
+    return ops.GradCarrier() if ok else None
 
 
 class _Basic(nn.Module):
@@ -55,8 +65,9 @@ class _Basic(nn.Module):
     def forward_nhwc(self, x):
         t = self.training
         idt = x if self.downsample is None else _conv_bn(x, self.downsample[0], self.downsample[1], None, t)
-        y = _conv_bn(x, self.conv1, self.bn1, "relu", t)
-        return _conv_bn(y, self.conv2, self.bn2, None, t, residual=idt)
+        c = _carrier(self, x, t)
+        y = _conv_bn(x, self.conv1, self.bn1, "relu", t, take_over=c)
+        return _conv_bn(y, self.conv2, self.bn2, None, t, residual=idt, hand_over=c)
 
 
 class _Bottleneck(nn.Module):
@@ -85,9 +96,10 @@ class _Bottleneck(nn.Module):
     def forward_nhwc(self, x):
         t = self.training
         idt = x if self.downsample is None else _conv_bn(x, self.downsample[0], self.downsample[1], None, t)
-        y = _conv_bn(x, self.conv1, self.bn1, "relu", t)
+        c = _carrier(self, x, t)
+        y = _conv_bn(x, self.conv1, self.bn1, "relu", t, take_over=c)
         y = _conv_bn(y, self.conv2, self.bn2, "relu", t)
-        return _conv_bn(y, self.conv3, self.bn3, None, t, residual=idt)
+        return _conv_bn(y, self.conv3, self.bn3, None, t, residual=idt, hand_over=c)
 
 
 RESNETS = {"resnet18": (_Basic, [2, 2, 2, 2]), "resnet34": (_Basic, [3, 4, 6, 3]),

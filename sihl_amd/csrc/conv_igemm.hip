@@ -43,6 +43,8 @@ struct ConvParams {
   int splits;       // > 1: split-K - grid.y splits each accumulate a slice of the K stages into `partial`
   float* partial;   // [splits][M][Cout] fp32 (caller workspace)
   long partial_bytes;
+  const void* add;  // optional tensor of the output's shape added in the epilogue (dense output only): the identity
+                    // branch's gradient riding on a residual block's first dgrad instead of a separate add kernel
 };
 
 bool g_force_reg = false;  // test hook: use the register-staged loader
@@ -144,6 +146,37 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t
   constexpr int CHUNKS = BN * (int)sizeof(T) / 16;  // 16-byte chunks per tile row
   const bool vec_ok = (p.Cout % VEC) == 0;
   const int hw_o = p.Ho * p.Wo;
+  if (p.add && vec_ok) {
+    // + addend (dense output): the addend chunks of U rows are requested together, THEN added and stored - one global
+    // round trip per U chunks instead of one per chunk (the naive loop made this epilogue latency-bound)
+    constexpr int ITER = BM * CHUNKS / NTHREADS, U = ITER < 8 ? ITER : 8;
+    static_assert(BM * CHUNKS % NTHREADS == 0 && ITER % U == 0, "tile / thread-count mismatch");
+    const T* __restrict__ addp = (const T*)p.add;
+    for (int it0 = 0; it0 < ITER; it0 += U) {
+      uint4 av[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = tid + (it0 + u) * NTHREADS;
+        const int row = idx / CHUNKS, ch = idx - row * CHUNKS;
+        const int m = m0 + row, co = n0 + ch * VEC;
+        av[u] = (m < p.M && co + VEC <= p.Cout) ? *(const uint4*)(addp + (long)m * p.Cout + co) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = tid + (it0 + u) * NTHREADS;
+        const int row = idx / CHUNKS, ch = idx - row * CHUNKS;
+        const int m = m0 + row, co = n0 + ch * VEC;
+        if (m >= p.M || co + VEC > p.Cout) continue;
+        float a[VEC], c[VEC];
+        unpack16(*(const uint4*)(epi + row * EPI_STRIDE + ch * 16), a, T());
+        unpack16(av[u], c, T());
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] += c[e];
+        *(uint4*)(out + (long)m * p.Cout + co) = pack16(a, T());
+      }
+    }
+    return;
+  }
   for (int idx = tid; idx < BM * CHUNKS; idx += NTHREADS) {
     const int row = idx / CHUNKS, ch = idx - row * CHUNKS;
     const int m = m0 + row, co = n0 + ch * VEC;
@@ -154,7 +187,11 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t
     if (vec_ok && co + VEC <= p.Cout) {
       *(uint4*)dst = *(const uint4*)src;
     } else {
-      for (int e = 0; e < VEC && co + e < p.Cout; ++e) dst[e] = ((const T*)src)[e];
+      for (int e = 0; e < VEC && co + e < p.Cout; ++e) {
+        float v = elem<T>::ld((const T*)src + e);
+        if (p.add) v += elem<T>::ld((const T*)p.add + (long)m * p.Cout + co + e);
+        elem<T>::st(dst + e, v);
+      }
     }
   }
 }
@@ -645,6 +682,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvPar
       else if (ACT == SIHL_ACT_SIGMOID) x = 1.f / (1.f + expf(-x));
       if (STATS == 2 && ok) { ssum[e] += x; ssq[e] += x * x; }
       o[e] = x * s2[e] + t2[e];
+      if (p.add && ok) o[e] += elem<T>::ld((const T*)p.add + (long)(mbase + k) * p.Cout + co + e);
     }
     if (ok) {
       T* dst = out + (long)(mbase + k) * p.Cout + co;
@@ -845,8 +883,8 @@ int sihl_conv2d_fwd_ws(const void* in, const void* wt, const float* bias, void* 
                        const float* pre_scale, const float* pre_shift, const float* post_scale,
                        const float* post_shift, int stats_mode, float* stats_ws, long stats_ws_bytes,
                        long out_image_stride, void* ws, long ws_bytes, hipStream_t stream);
-int sihl_conv2d_dgrad_ws(const void* dout, const void* wt_t, void* din, int N, int H, int W, int Cin, int Cout, int KH,
-                         int KW, int stride, int pad, int dil, int dtype, void* ws, long ws_bytes,
+int sihl_conv2d_dgrad_ws(const void* dout, const void* wt_t, void* din, const void* add, int N, int H, int W, int Cin,
+                         int Cout, int KH, int KW, int stride, int pad, int dil, int dtype, void* ws, long ws_bytes,
                          hipStream_t stream);
 
 // Test hook: 1 = use the register-staged loader instead of LDS-DMA (both are kept parity-tested).
@@ -923,6 +961,7 @@ int sihl_conv2d_fwd_ws(const void* in, const void* wt, const float* bias, void* 
     if (stats_ws_bytes < (long)sihl_conv2d_stat_rows(M) * 2 * Cout * (long)sizeof(float)) return SIHL_EWS;
   }
   p.splits = 1; p.partial = (float*)ws; p.partial_bytes = ws ? ws_bytes : 0;
+  p.add = nullptr;
   if (dtype == SIHL_F32) return dispatch<float>(p, stream);
   if (dtype == SIHL_BF16) return dispatch<bf16_t>(p, stream);
   return SIHL_EARG;
@@ -932,13 +971,15 @@ int sihl_conv2d_fwd_ws(const void* in, const void* wt, const float* bias, void* 
 // wt_t = sihl_weight_flip_transpose(w, flip=1) is [Cin][KH][KW][Cout].  dout is read as if zero-dilated by `stride`.
 int sihl_conv2d_dgrad(const void* dout, const void* wt_t, void* din, int N, int H, int W, int Cin, int Cout, int KH,
                       int KW, int stride, int pad, int dil, int dtype, hipStream_t stream) {
-  return sihl_conv2d_dgrad_ws(dout, wt_t, din, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, dtype, nullptr, 0, stream);
+  return sihl_conv2d_dgrad_ws(dout, wt_t, din, nullptr, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, dtype, nullptr, 0,
+                              stream);
 }
 
-// sihl_conv2d_dgrad with caller scratch: ws_bytes >= sihl_conv2d_ws_bytes(N, Ho, Wo, Cout, Cin, KH, KW, 1, ...) of
-// the equivalent forward problem (output = din) enables split-K.
-int sihl_conv2d_dgrad_ws(const void* dout, const void* wt_t, void* din, int N, int H, int W, int Cin, int Cout, int KH,
-                         int KW, int stride, int pad, int dil, int dtype, void* ws, long ws_bytes,
+// sihl_conv2d_dgrad with caller scratch (ws_bytes >= sihl_conv2d_ws_bytes(N, Ho, Wo, Cout, Cin, KH, KW, 1, ...) of the
+// equivalent forward problem (output = din) enables split-K) and an optional addend: din = dgrad + add, `add` a dense
+// [N][H][W][Cin] tensor of the same dtype (the identity-branch gradient of a residual block), or NULL.
+int sihl_conv2d_dgrad_ws(const void* dout, const void* wt_t, void* din, const void* add, int N, int H, int W, int Cin,
+                         int Cout, int KH, int KW, int stride, int pad, int dil, int dtype, void* ws, long ws_bytes,
                          hipStream_t stream) {
   if (!dout || !wt_t || !din || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 ||
       stride <= 0 || dil <= 0 || pad < 0)
@@ -965,6 +1006,7 @@ int sihl_conv2d_dgrad_ws(const void* dout, const void* wt_t, void* din, int N, i
   p.dbg = 0;
   p.out_image_stride = (long)H * W * Cin;
   p.splits = 1; p.partial = (float*)ws; p.partial_bytes = ws ? ws_bytes : 0;
+  p.add = add;
   if (dtype == SIHL_F32) return dispatch<float>(p, stream);
   if (dtype == SIHL_BF16) return dispatch<bf16_t>(p, stream);
   return SIHL_EARG;
