@@ -284,29 +284,36 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(const WgradParams p
   auto compute = [&](int buf, bool more, unsigned abase) {
     const char* As = smem + buf * STAGE;
     const char* Bs = As + TILE;
-#pragma unroll
-    for (int ks = 0; ks < WKP / 16; ++ks) {
+    // operand fragments are double-buffered in registers: the transposed reads of k-step ks+1 are in flight while
+    // k-step ks multiplies (reading and multiplying back to back left the matrix pipe idle for an LDS round trip
+    // per k-step)
+    bf16x8_t a[2][4], bq[2][2];
+    auto load_frags = [&](int ks, int slot) {
       const int row = ks * 16 + rowsel;
-      bf16x8_t a[4], bq[2];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int off = tr_addr(row, (wm * 128 + t * 32) * 2);
         s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(As + off));
         s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(As + off + 4 * WROW));
-        a[t] = __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        a[slot][t] = __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int off = tr_addr(row, (wn * 64 + t * 32) * 2);
         s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Bs + off));
         s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Bs + off + 4 * WROW));
-        bq[t] = __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        bq[slot][t] = __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
       }
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < WKP / 16; ++ks) {
+      if (ks + 1 < WKP / 16) load_frags(ks + 1, (ks + 1) & 1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bq[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], bq[ks & 1][j], acc[i][j], 0, 0, 0);
       // the next stage's DMA goes out behind the first two k-steps' MFMAs (front-loaded, as in conv_igemm)
       if (more && ks < 2) {
 #pragma unroll
