@@ -72,7 +72,7 @@ template <> __device__ __forceinline__ void mma_step<float>(f32x16_t& c, const u
 
 // Shared epilogue: bias -> [stats] -> pre-affine -> act -> [stats] -> post-affine, LDS transpose, row stores.
 // ACT and STATS are compile-time inside the element loop (a runtime switch there costs an expf per element).
-template <typename T, int BM, int BN, int WM, int WN, int ACT, int STATS>
+template <typename T, int BM, int BN, int WM, int WN, int ACT, int STATS, bool ADD = false>
 __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32],
                                                    char* smem, int tile_m, int m0, int n0) {
   constexpr int VEC = 16 / (int)sizeof(T);
@@ -146,9 +146,11 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t
   constexpr int CHUNKS = BN * (int)sizeof(T) / 16;  // 16-byte chunks per tile row
   const bool vec_ok = (p.Cout % VEC) == 0;
   const int hw_o = p.Ho * p.Wo;
-  if (p.add && vec_ok) {
+  if constexpr (ADD) if (vec_ok) {
     // + addend (dense output): the addend chunks of U rows are requested together, THEN added and stored - one global
-    // round trip per U chunks instead of one per chunk (the naive loop made this epilogue latency-bound)
+    // round trip per U chunks instead of one per chunk (the naive loop made this epilogue latency-bound).  The U
+    // chunks cost 4 U registers on top of the main loop's peak, which is why this path is its own kernel
+    // instantiation (ADD): compiled into every kernel it took a wave per SIMD from all of them.
     constexpr int ITER = BM * CHUNKS / NTHREADS, U = ITER < 8 ? ITER : 8;
     static_assert(BM * CHUNKS % NTHREADS == 0 && ITER % U == 0, "tile / thread-count mismatch");
     const T* __restrict__ addp = (const T*)p.add;
@@ -189,7 +191,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t
     } else {
       for (int e = 0; e < VEC && co + e < p.Cout; ++e) {
         float v = elem<T>::ld((const T*)src + e);
-        if (p.add) v += elem<T>::ld((const T*)p.add + (long)m * p.Cout + co + e);
+        if (ADD) v += elem<T>::ld((const T*)p.add + (long)m * p.Cout + co + e);
         elem<T>::st(dst + e, v);
       }
     }
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 // latency per 64-deep stage and take 3-4.
 template <int N> __device__ __forceinline__ void wait_vm_keep() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int BM, int BN, int WM, int WN, bool DIL, int NBUF>
+template <typename T, int BM, int BN, int WM, int WN, bool DIL, int NBUF, bool ADD = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(const ConvParams p) {
   constexpr int NTHREADS = WM * WN * 64;
   constexpr int VEC = 16 / (int)sizeof(T);
@@ -625,7 +627,31 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(const Conv
     }
     return;
   }
-  conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, tile_m, m0, n0);
+  if constexpr (ADD) conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_NONE, 0, true>(p, acc, smem, tile_m, m0, n0);
+  else conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, tile_m, m0, n0);
+}
+
+// out += add over n elements (fallback for tile configurations without an ADD instantiation)
+template <typename T>
+__global__ void conv_add_inplace_kernel(T* __restrict__ out, const T* __restrict__ add, long nvec) {
+  constexpr int V = 16 / (int)sizeof(T);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    float a[V], b[V];
+    unpack16(*(const uint4*)(out + i * V), a, T());
+    unpack16(*(const uint4*)(add + i * V), b, T());
+#pragma unroll
+    for (int e = 0; e < V; ++e) a[e] += b[e];
+    *(uint4*)(out + i * V) = pack16(a, T());
+  }
+}
+
+template <typename T>
+void launch_add_inplace(const ConvParams& p, hipStream_t stream) {
+  constexpr int V = 16 / (int)sizeof(T);
+  const long nvec = (long)p.M * p.Cout / V;  // dense output, Cout % V == 0
+  long g = (nvec + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(conv_add_inplace_kernel<T>, dim3((unsigned)g), dim3(256), 0, stream, (T*)p.out, (const T*)p.add, nvec);
 }
 
 // Second half of a split-K conv: out = epilogue(sum_s partial[s]) with the same bias / statistics / affine / activation
@@ -734,8 +760,17 @@ int launch_dma(const ConvParams& p0, hipStream_t stream) {
   constexpr int LDS = STAGES2 > EPI ? STAGES2 : EPI;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
+  // the addend epilogue exists for the tiles the identity-block dgrads use; other configurations add in a second pass
+  constexpr bool CAN_ADD = (BM == 128 && BN == 128 && NBUF == 1) || (BM == 256 && BN == 256);
+  const bool fused_add = p.add && CAN_ADD && p.splits == 1 && p.in_dilate == 1 && p.act == SIHL_ACT_NONE &&
+                         p.stats_mode == 0 && !p.bias && !p.pre_scale && !p.post_scale;
+  const void* late_add = (p.add && !fused_add && p.splits == 1) ? p.add : nullptr;  // split-K adds in its finisher
+  if (late_add) p.add = nullptr;
   auto kern = p.in_dilate > 1 ? conv_igemm_dma_kernel<T, BM, BN, WM, WN, true, NBUF>
                               : conv_igemm_dma_kernel<T, BM, BN, WM, WN, false, NBUF>;
+  if constexpr (CAN_ADD) {
+    if (fused_add) kern = conv_igemm_dma_kernel<T, BM, BN, WM, WN, false, NBUF, true>;
+  }
   if (!attr_set) {
     hipError_t e0 = hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<T, BM, BN, WM, WN, true, NBUF>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -743,6 +778,11 @@ int launch_dma(const ConvParams& p0, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<T, BM, BN, WM, WN, false, NBUF>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
+    if constexpr (CAN_ADD) {
+      e = hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<T, BM, BN, WM, WN, false, NBUF, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (e != hipSuccess) return (int)e;
+    }
     attr_set = true;
   }
   const double flops = 2.0 * p.M * (double)p.Cout * p.KH * p.KW * p.Cin;
@@ -750,6 +790,7 @@ int launch_dma(const ConvParams& p0, hipStream_t stream) {
   sihl_prof_begin(SIHL_PROF_CONV, sizeof(T) == 2 ? SIHL_BF16 : SIHL_F32, flops, bytes, stream);
   hipLaunchKernelGGL(kern, dim3(p.gridM * p.gridN, p.splits), dim3(WM * WN * 64), LDS, stream, p);
   if (p.splits > 1) launch_splitk_epilogue<T>(p, stream);
+  if (late_add) { p.add = late_add; launch_add_inplace<T>(p, stream); }
   sihl_prof_end(stream);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
@@ -774,7 +815,10 @@ int launch_reg(const ConvParams& p0, hipStream_t stream) {
   const double flops = 2.0 * p.M * (double)p.Cout * p.KH * p.KW * p.Cin;
   const double bytes = ((double)p.N * p.H * p.W * p.Cin + (double)p.M * p.Cout + (double)p.Cout * p.KH * p.KW * p.Cin) * sizeof(T);
   sihl_prof_begin(SIHL_PROF_CONV, sizeof(T) == 2 ? SIHL_BF16 : SIHL_F32, flops, bytes, stream);
+  const void* late_add = p.add;
+  p.add = nullptr;
   hipLaunchKernelGGL(kern, dim3(p.gridM * p.gridN), dim3(256), LDS, stream, p);
+  if (late_add) { p.add = late_add; launch_add_inplace<T>(p, stream); }
   sihl_prof_end(stream);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
