@@ -157,6 +157,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
   };
 
+  // ONE LDS stage: the registers holding the next stage's loads are the second buffer.  40 KB instead of 80 KB lets
+  // three workgroups share a CU and overlap each other's load / multiply phases (an extra barrier per stage buys it).
   if (nstages > 0) {
     load_regs(0);
     store_lds(0);
@@ -164,8 +166,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     for (int s = 0; s < nstages; ++s) {
       const bool more = s + 1 < nstages;
       if (more) load_regs(s + 1);
-      compute(s & 1);
-      if (more) store_lds((s + 1) & 1);
+      compute(0);
+      __syncthreads();
+      if (more) store_lds(0);
       __syncthreads();
     }
   }
@@ -590,7 +593,7 @@ int launch_dma(WgradParams p, hipStream_t stream) {
 
 template <typename T>
 int launch(WgradParams p, hipStream_t stream) {
-  constexpr int LDS = 2 * 2 * wg_cfg<T>::KP * wg_cfg<T>::ROWB;
+  constexpr int LDS = 2 * wg_cfg<T>::KP * wg_cfg<T>::ROWB;  // one stage: dout tile + input tile
   static bool attr_set = false;
   auto kern = conv_wgrad_kernel<T>;
   if (!attr_set) {
