@@ -34,5 +34,14 @@ class SihlModel(nn.Module):
         """Move to ``device`` with 4-d parameters channels-last, the layout the HIP conv kernels consume."""
         return self.to(device).to(memory_format=torch.channels_last)
 
+    def prepare_inference(self, dtype: torch.dtype = torch.bfloat16):
+        """bf16 inference: make the bf16 operand copies of every conv / linear weight once (one kernel) instead of
+        casting per layer per call.  Returns the PreparedWeights handle; call its ``refresh()`` after changing weights
+        (``load_state_dict`` bumps the version stamps, so stale copies are never used silently)."""
+        from sihl_amd import ops
+
+        self._prepared = ops.PreparedWeights(self, dtype)
+        return self._prepared
+
     def num_parameters(self, trainable_only: bool = False) -> int:
         return sum(p.numel() for p in self.parameters() if p.requires_grad or not trainable_only)
