@@ -13,6 +13,7 @@ PyTorch-ROCm (MIOpen/CK), which SURVEY §8 a2 allows ("not a hand-kernel target"
 iteration.  The 7x7 stem (3 input channels) + max-pool stay on PyTorch-ROCm in both modes.  CPU tensors (BASELINE
 config 1, "stock PyTorch plumbing") always run through plain torch ops with the same parameters.
 """
+import os
 from typing import List, Optional
 
 import torch
@@ -39,7 +40,7 @@ def _carrier(block, x: Tensor, training: bool):
     """A GradCarrier for identity blocks in training: the shortcut's gradient then rides on conv1's dgrad.  Needs the
     first conv to produce an input gradient of x's shape (stride 1, x requires grad, conv1 trainable path)."""
     ok = (training and block.downsample is None and torch.is_grad_enabled() and x.requires_grad
-          and block.conv1.stride[0] == 1 and not __import__("os").environ.get("SIHL_NO_GRAD_CARRIER"))
+          and block.conv1.stride[0] == 1 and not os.environ.get("SIHL_NO_GRAD_CARRIER"))  # env: A/B switch
     return ops.GradCarrier() if ok else None
 
 
