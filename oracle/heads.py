@@ -7,6 +7,7 @@ TEST INFRASTRUCTURE ONLY.  Reference files followed (relative to
   heads/semantic_segmentation.py:123-182     SPPM, UAFM
   heads/multiclass_classification.py:47-52   MulticlassClassification (config-1 plumbing)
   heads/instance_segmentation.py:15-278      InstanceSegmentation (CondInst mask decode)
+  heads/depth_estimation.py:15-122           DepthEstimation (AdaBins on the SemanticSegmentation decoder; 8f rank 4)
 torchvision 0.21 ``ops.complete_box_iou`` / ``complete_box_iou_loss`` are NOT in
 the container; they are restated from the published CIoU definition (SURVEY.md
 App. B) and are "parity unpinned".
@@ -451,6 +452,65 @@ class SemanticSegmentation(nn.Module):
     def training_step(self, inputs: List[Tensor], targets: Tensor):
         logits = F.interpolate(self.get_logits(inputs), size=targets.shape[1:])
         return F.cross_entropy(logits, targets, ignore_index=self.ignore_index), {}
+
+
+# --------------------------------------------------------------------------- depth estimation (AdaBins)
+DEPTH_EPS = 1e-5  # sihl.utils.EPS (utils/__init__.py:20)
+
+
+class DepthEstimation(SemanticSegmentation):
+    """Per-image adaptive bins (a conv tower + global average on the top level gives bin widths) weighted by the
+    per-pixel bin scores of the segmentation decoder (depth_estimation.py:15-122)."""
+
+    def __init__(self, in_channels: List[int], lower_bound: float, upper_bound: float, bottom_level: int = 3,
+                 top_level: int = 5, num_channels: int = 256, num_layers: int = 1, num_bins: int = 256):
+        assert lower_bound < upper_bound and num_bins > 1 and num_layers > 0
+        super().__init__(in_channels=in_channels, num_classes=num_bins, num_channels=num_channels,
+                         bottom_level=bottom_level, top_level=top_level, num_layers=num_layers)
+        self.num_bins, self.lower_bound, self.upper_bound = num_bins, lower_bound, upper_bound
+        self.bin_head = nn.Sequential(SequentialConvBlocks(in_channels[top_level], num_channels, num_layers),
+                                      nn.Conv2d(num_channels, num_bins, kernel_size=1), nn.AdaptiveAvgPool2d(1),
+                                      nn.Flatten())
+        stride = 2 ** bottom_level
+        self.output_shapes = {"depth_maps": ("batch_size", f"height/{stride}", f"width/{stride}")}
+
+    def normalize(self, x: Tensor) -> Tensor:
+        return (x - self.lower_bound) / (self.upper_bound - self.lower_bound)
+
+    def denormalize(self, x: Tensor) -> Tensor:
+        return x * (self.upper_bound - self.lower_bound) + self.lower_bound
+
+    def get_bin_centers(self, inputs: List[Tensor]) -> Tensor:
+        widths = self.bin_head(inputs[self.top_level]).relu() + DEPTH_EPS
+        widths = widths / widths.sum(dim=1, keepdim=True)
+        return widths.cumsum(dim=1) - widths / 2
+
+    def get_depth_map(self, inputs: List[Tensor], bin_centers: Tensor) -> Tensor:
+        weights = self.get_logits(inputs).relu() + DEPTH_EPS
+        weights = weights / weights.sum(dim=1, keepdim=True)
+        return (bin_centers[:, :, None, None] * weights).sum(dim=1, keepdim=True).clamp(0, 1)
+
+    def forward(self, inputs: List[Tensor]) -> Tensor:
+        depth = self.denormalize(self.get_depth_map(inputs, self.get_bin_centers(inputs)))
+        return F.interpolate(depth, size=inputs[0].shape[2:]).squeeze(1)
+
+    def training_step(self, inputs: List[Tensor], targets: Tensor, masks: Tensor):
+        B = targets.shape[0]
+        masks, targets = masks[:, None], self.normalize(targets[:, None])
+        centers = self.get_bin_centers(inputs)
+        depth = self.get_depth_map(inputs, centers)
+        pred_shape = depth.shape[2:]
+        depth = F.interpolate(depth, size=targets.shape[2:])
+        g = (depth[masks] + DEPTH_EPS).log() - (targets[masks] + DEPTH_EPS).log()
+        pix_loss = torch.sqrt(g.var() + 0.15 * g.mean().pow(2)) * 10  # scale-invariant log loss
+        masks = F.interpolate(masks.to(torch.uint8), size=pred_shape, mode="nearest") > 0
+        targets = F.interpolate(targets, size=pred_shape)
+        hist = []
+        for b in range(B):  # bidirectional chamfer distance between bin centres and the valid target depths
+            dist = (centers[b][None, :] - targets[b][masks[b]][:, None]).pow(2)
+            hist.append(dist.min(dim=1).values.mean() + dist.min(dim=0).values.mean())
+        hist_loss = torch.stack(hist).mean()
+        return pix_loss + hist_loss, {"pixel_loss": pix_loss, "hist_loss": hist_loss}
 
 
 # --------------------------------------------------------------------------- config-1 plumbing head

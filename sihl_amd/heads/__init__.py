@@ -1,4 +1,5 @@
 # Same public names as the reference's ``sihl.heads`` for the hot-path heads (src/sihl/heads/__init__.py).
+from sihl_amd.heads.depth_estimation import DepthEstimation  # noqa: F401
 from sihl_amd.heads.instance_segmentation import InstanceSegmentation  # noqa: F401
 from sihl_amd.heads.mlp import MLP  # noqa: F401
 from sihl_amd.heads.multiclass_classification import MulticlassClassification  # noqa: F401

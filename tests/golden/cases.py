@@ -390,3 +390,43 @@ def _is_train_run(m, inp):
 
 
 _register("iseg_training_step", _is_build, _is_inputs, _is_train_run, True, needs="iseg")
+
+
+# ------------------------------------------------------------------ depth-estimation head
+def _depth_build(ns):
+    return perturb_(ns.DepthEstimation(_SS_CH, lower_bound=0.5, upper_bound=10.0, bottom_level=3, top_level=5,
+                                       num_channels=32, num_layers=1, num_bins=16), 23, scale=0.5)
+
+
+def _depth_inputs():
+    return _ss_inputs()
+
+
+def _depth_forward_run(m, inp):
+    with torch.no_grad():
+        return {"depth": m(inp["levels"]), "bin_centers": m.get_bin_centers(inp["levels"])}
+
+
+_register("depth_forward_eval", _depth_build, _depth_inputs, _depth_forward_run, False, needs="depth")
+
+
+def _depth_train_run(m, inp):
+    lv = [t.clone().requires_grad_(i >= 3) for i, t in enumerate(inp["levels"])]
+    dev = lv[3].device
+    H, W = lv[0].shape[2:]
+    g = torch.Generator().manual_seed(77)
+    targets = (0.5 + 9.5 * torch.rand(lv[0].shape[0], H, W, generator=g)).to(dev)
+    masks = (torch.rand(lv[0].shape[0], H, W, generator=g) > 0.3).to(dev)
+    loss, metrics = m.training_step(lv, targets, masks)
+    res = {"loss": loss, **metrics}
+    params = [(n, p) for n, p in m.named_parameters()]
+    grads = torch.autograd.grad(loss, lv[3:] + [p for _, p in params], allow_unused=True)
+    for i, gi in enumerate(grads[:len(lv) - 3]):
+        res[f"gin{i}"] = gi
+    for (n, _), gp in zip(params, grads[len(lv) - 3:]):
+        if gp is not None:
+            res[f"gp.{n}"] = gp
+    return res
+
+
+_register("depth_training_step", _depth_build, _depth_inputs, _depth_train_run, True, needs="depth")

@@ -84,7 +84,13 @@ def load_reference():
             if isinstance(v, type) and v.__module__ == mod.__name__:
                 setattr(layers, k, v)
                 setattr(ns, k, v)
-    for name in ("object_detection", "semantic_segmentation", "instance_segmentation"):
+    utils = types.ModuleType("sihl.utils")
+    utils.EPS = 1e-5  # the one constant depth_estimation.py takes from sihl/utils/__init__.py:20
+    sys.modules["sihl.utils"] = utils
+    tmr = types.ModuleType("torchmetrics.regression")
+    tmr.MeanAbsoluteError, tmr.MeanSquaredError = type("MeanAbsoluteError", (), {}), type("MeanSquaredError", (), {})
+    sys.modules["torchmetrics.regression"] = tmr
+    for name in ("object_detection", "semantic_segmentation", "instance_segmentation", "depth_estimation"):
         mod = _load(f"sihl.heads.{name}", f"heads/{name}.py")
         for k, v in vars(mod).items():
             if isinstance(v, type) and v.__module__ == mod.__name__:
@@ -103,7 +109,7 @@ def _flatten(prefix, obj, out):
 
 
 PINNED = {"layers": "reference-unmodified", "fpn": "reference+tv-standins",
-          "od": "reference+tv-standins", "semseg": "reference+tv-standins", "iseg": "reference+tv-standins"}
+          "od": "reference+tv-standins", "semseg": "reference+tv-standins", "iseg": "reference+tv-standins", "depth": "reference+tv-standins"}
 
 
 def main(argv):
