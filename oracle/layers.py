@@ -10,6 +10,7 @@ Reference files followed (relative to /root/reference/src/sihl):
   layers/scalers.py:16-56       AntialiasedDownscaler / Interpolate / SimpleUpscaler
   layers/bifpn.py:10-97         FastNormalizedFusion / BiFPNLayer / BiFPN
   layers/fpn.py:8-55            FPN
+  layers/hybrid_encoder.py:14-134   HybridEncoder / RepVGGBlock / CSPRepLayer (+ utils/__init__.py:95-138 sine embedding)
 torchvision 0.21 building blocks restated from their documented structure
 (SURVEY.md App. B): ops.Conv2dNormActivation, ops.MLP.
 """
@@ -269,4 +270,96 @@ class FPN(nn.Module):
         for down in self.extra_downscalers:
             td.append(down(td[-1]))
         outs = [conv(t) for conv, t in zip(self.out_convs, td)]
+        return list(inputs[: self.bottom_level]) + outs + list(inputs[self.top_level + 1:])
+
+
+# --------------------------------------------------------------------------- HybridEncoder (RT-DETR style neck)
+def sine_embedding_2d_grid(height: int, width: int, dim: int, temperature: float = 10000.0, device=None) -> Tensor:
+    """(h, w, dim) sinusoidal position code: first half of the channels encodes y, second half x, each half
+    [sin | cos] over dim/4 geometric frequencies (utils/__init__.py:95-138)."""
+    assert dim % 4 == 0
+    quarter = dim // 4
+    freq = torch.exp(torch.arange(quarter, dtype=torch.float32, device=device) * -(np.log(temperature) / (quarter - 1)))
+    ys = torch.arange(height, dtype=torch.float32, device=device)[:, None, None] * freq
+    xs = torch.arange(width, dtype=torch.float32, device=device)[None, :, None] * freq
+    ys, xs = ys.expand(height, width, quarter), xs.expand(height, width, quarter)
+    return torch.cat([ys.sin(), ys.cos(), xs.sin(), xs.cos()], dim=-1)
+
+
+class RepVGGBlock(nn.Module):
+    """silu(conv3x3+BN(x) + conv1x1+BN(x) + BN(x))  (hybrid_encoder.py:108-117)."""
+
+    def __init__(self, num_channels: int):
+        super().__init__()
+        self.conv1 = Conv2dNormActivation(num_channels, num_channels, 3, activation_layer=None)
+        self.conv2 = Conv2dNormActivation(num_channels, num_channels, 1, activation_layer=None)
+        self.identity = nn.BatchNorm2d(num_channels)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return F.silu(self.conv1(x) + self.conv2(x) + self.identity(x))
+
+
+class CSPRepLayer(nn.Module):
+    """Two 1x1 conv+BN+SiLU branches of the concatenated pair; one goes through RepVGG blocks (:120-134)."""
+
+    def __init__(self, in_channels: int, out_channels: int, num_layers: int = 3):
+        super().__init__()
+        self.conv1 = Conv2dNormActivation(in_channels, out_channels, 1, activation_layer=nn.SiLU)
+        self.conv2 = Conv2dNormActivation(in_channels, out_channels, 1, activation_layer=nn.SiLU)
+        self.bottlenecks = nn.Sequential(*[RepVGGBlock(out_channels) for _ in range(num_layers)])
+
+    def forward(self, x1: Tensor, x2: Tensor) -> Tensor:
+        x = torch.cat([x1, x2], dim=1)
+        return self.bottlenecks(self.conv1(x)) + self.conv2(x)
+
+
+class HybridEncoder(nn.Module):
+    """1x1 projections, one pre-norm transformer encoder layer on the coarsest projected level (with a sinusoidal
+    position code, residual around the whole encoder), top-down path (1x1 conv, nearest x2, CSPRep fusion), optional
+    stride-2 extra levels, bottom-up path (stride-2 3x3 conv, CSPRep fusion)  (hybrid_encoder.py:14-105)."""
+
+    def __init__(self, in_channels: List[int], out_channels: int, bottom_level: int, top_level: int):
+        super().__init__()
+        assert out_channels % 2 == 0
+        self.in_channels = in_channels
+        self.top_in_level = min(top_level, len(in_channels) - 1)
+        self.bottom_level, self.top_level = bottom_level, top_level
+        self.num_channels = out_channels
+        self.out_channels = list(in_channels)
+        self.out_channels[bottom_level: top_level + 1] = [out_channels] * (top_level - bottom_level + 1)
+        self.input_projections = nn.ModuleList(
+            Conv2dNormActivation(in_channels[l], out_channels, 1, activation_layer=None)
+            for l in range(bottom_level, self.top_in_level + 1))
+        self.encoder = nn.TransformerEncoder(
+            nn.TransformerEncoderLayer(out_channels, nhead=8, dim_feedforward=4 * out_channels, dropout=0,
+                                       activation="gelu", batch_first=True, norm_first=True), num_layers=1)
+        self.up_convs, self.up_fusions = nn.ModuleList(), nn.ModuleList()
+        for _ in range(self.top_in_level, bottom_level, -1):
+            self.up_convs.append(Conv2dNormActivation(out_channels, out_channels, 1, activation_layer=nn.SiLU))
+            self.up_fusions.append(CSPRepLayer(out_channels * 2, out_channels))
+        self.extra_downscalers = nn.ModuleList(
+            Conv2dNormActivation(out_channels, out_channels, 3, stride=2, activation_layer=nn.SiLU)
+            for _ in range(top_level - len(in_channels) + 1))
+        self.down_convs, self.down_fusions = nn.ModuleList(), nn.ModuleList()
+        for _ in range(bottom_level, top_level):
+            self.down_convs.append(Conv2dNormActivation(out_channels, out_channels, 3, stride=2, activation_layer=nn.SiLU))
+            self.down_fusions.append(CSPRepLayer(out_channels * 2, out_channels))
+
+    def forward(self, inputs: List[Tensor]) -> List[Tensor]:
+        xs = [proj(x) for proj, x in zip(self.input_projections, inputs[self.bottom_level: self.top_in_level + 1])]
+        B, C, h, w = xs[-1].shape
+        pos = sine_embedding_2d_grid(h, w, self.num_channels, device=xs[-1].device).permute(2, 0, 1)[None]
+        tokens = (xs[-1] + pos).flatten(2).transpose(1, 2)
+        tokens = tokens + self.encoder(tokens)
+        xs[-1] = tokens.transpose(1, 2).reshape(B, C, h, w)
+        inner = [xs[-1]]
+        for i, (conv, fuse) in enumerate(zip(self.up_convs, self.up_fusions)):
+            high = conv(inner[0])
+            inner[0] = high
+            inner.insert(0, fuse(F.interpolate(high, scale_factor=2), xs[len(xs) - 2 - i]))
+        for down in self.extra_downscalers:
+            inner.append(down(inner[-1]))
+        outs = [inner[0]]
+        for i, (conv, fuse) in enumerate(zip(self.down_convs, self.down_fusions)):
+            outs.append(fuse(conv(outs[-1]), inner[i + 1]))
         return list(inputs[: self.bottom_level]) + outs + list(inputs[self.top_level + 1:])

@@ -430,3 +430,13 @@ def _depth_train_run(m, inp):
 
 
 _register("depth_training_step", _depth_build, _depth_inputs, _depth_train_run, True, needs="depth")
+
+
+# ------------------------------------------------------------------ HybridEncoder neck (the examples' default neck)
+_HE_CH = [3, 8, 16, 24, 40, 48]
+_neck("hybrid_3to6_eval", lambda ns: perturb_(ns.HybridEncoder(list(_HE_CH), 32, 3, 6), 31, scale=0.3),
+      _HE_CH, 128, range(3, 6), 2, False, 120, [3, 4, 5, 6])
+_neck("hybrid_3to6_train", lambda ns: perturb_(ns.HybridEncoder(list(_HE_CH), 32, 3, 6), 31, scale=0.3),
+      _HE_CH, 128, range(3, 6), 2, True, 121, [3, 4, 5, 6])
+for c in ("hybrid_3to6_eval", "hybrid_3to6_train"):
+    CASES[c].needs = "hybrid"

@@ -11,7 +11,8 @@ imported (torchvision / torchmetrics / timm / lightning are absent), so bare
 package objects are registered for ``sihl``, ``sihl.layers`` and ``sihl.heads``
 and each hot-path file is executed with importlib from where it lies:
   layers/{convblocks,pooling,scalers,bifpn}.py  - need only torch/einops/numpy: run UNMODIFIED
-  layers/fpn.py, heads/object_detection.py, heads/semantic_segmentation.py, heads/instance_segmentation.py
+  layers/fpn.py, layers/hybrid_encoder.py, utils/__init__.py (+ polygon_iou, pck, f1), heads/object_detection.py,
+  heads/semantic_segmentation.py, heads/instance_segmentation.py, heads/depth_estimation.py
       - additionally import ``torchvision.ops`` / ``torchmetrics``.  Stand-in modules are
         registered for those imports: ``ops.Conv2dNormActivation`` / ``ops.MLP`` (compositions
         of torch.nn layers, documented structure) and ``ops.complete_box_iou[_loss]`` (published
@@ -78,15 +79,28 @@ def load_reference():
                         "torchmetrics.detection.mean_ap": tmm})
 
     ns = types.SimpleNamespace()
-    for name in ("convblocks", "pooling", "scalers", "bifpn", "fpn"):
+    LAYER_FILES = ("convblocks", "pooling", "scalers", "bifpn", "fpn")
+    for name in LAYER_FILES:
         mod = _load(f"sihl.layers.{name}", f"layers/{name}.py")
         for k, v in vars(mod).items():
             if isinstance(v, type) and v.__module__ == mod.__name__:
                 setattr(layers, k, v)
                 setattr(ns, k, v)
-    utils = types.ModuleType("sihl.utils")
-    utils.EPS = 1e-5  # the one constant depth_estimation.py takes from sihl/utils/__init__.py:20
-    sys.modules["sihl.utils"] = utils
+    # sihl/utils/__init__.py itself runs unmodified once torchmetrics.Metric / torchvision.ops.box_iou resolve (inert
+    # placeholders: only the metric classes use them); it provides EPS and sine_embedding_2d_grid
+    tm.Metric = type("Metric", (), {})
+    ops.box_iou = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError("placeholder"))
+    tv.__path__ = []
+    _pkg("sihl.utils", REF + "/utils")
+    for sub in ("polygon_iou", "pck", "f1"):
+        _load(f"sihl.utils.{sub}", f"utils/{sub}.py")
+    utils = _load("sihl.utils", "utils/__init__.py")
+    sihl.utils = utils
+    mod = _load("sihl.layers.hybrid_encoder", "layers/hybrid_encoder.py")  # needs sihl.utils + tv stand-ins
+    for k, v in vars(mod).items():
+        if isinstance(v, type) and v.__module__ == mod.__name__:
+            setattr(layers, k, v)
+            setattr(ns, k, v)
     tmr = types.ModuleType("torchmetrics.regression")
     tmr.MeanAbsoluteError, tmr.MeanSquaredError = type("MeanAbsoluteError", (), {}), type("MeanSquaredError", (), {})
     sys.modules["torchmetrics.regression"] = tmr
@@ -109,7 +123,7 @@ def _flatten(prefix, obj, out):
 
 
 PINNED = {"layers": "reference-unmodified", "fpn": "reference+tv-standins",
-          "od": "reference+tv-standins", "semseg": "reference+tv-standins", "iseg": "reference+tv-standins", "depth": "reference+tv-standins"}
+          "od": "reference+tv-standins", "semseg": "reference+tv-standins", "iseg": "reference+tv-standins", "depth": "reference+tv-standins", "hybrid": "reference+tv-standins"}
 
 
 def main(argv):

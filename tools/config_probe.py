@@ -61,3 +61,13 @@ model = sihl_amd.SihlModel(bb, neck, [od, ss]).to(dev).to(memory_format=torch.ch
 images = torch.rand(16, 3, 640, 640, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
 targets = [boxes_targets(16, 640, g), torch.randint(0, 21, (16, 640, 640), generator=g).to(dev)]
 run("configs[4]-like ResNet50+BiFPN+{ObjectDetection,SemanticSegmentation} bs16 640^2 bf16", model, images, targets, torch.bfloat16)
+del model
+torch.cuda.empty_cache()
+torch.cuda.reset_peak_memory_stats()
+# ---- the reference examples' default neck
+bb = sihl_amd.ResNetBackbone("resnet50", top_level=5)
+neck = sihl_amd.layers.HybridEncoder(bb.out_channels, 256, 3, 7)
+od = sihl_amd.heads.ObjectDetection(neck.out_channels, num_classes=80, bottom_level=3, top_level=7)
+model = sihl_amd.SihlModel(bb, neck, [od]).to(dev).to(memory_format=torch.channels_last)
+images = torch.rand(32, 3, 512, 512, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+run("ResNet50+HybridEncoder(3-7)+ObjectDetection bs32 512^2 bf16", model, images, [boxes_targets(32, 512, g)], torch.bfloat16)
