@@ -223,13 +223,23 @@ class ObjectDetection(nn.Module):
         return assign, torch.where(valid, rel, o2m)
 
     def on_validation_start(self) -> None:
+        from sihl_amd.metrics import BoxMeanAveragePrecision
+
         self._val_losses: List[Tensor] = []
+        self.map_computer = BoxMeanAveragePrecision([1, min(self.max_instances, 10), self.max_instances])
 
     def validation_step(self, inputs, classes, boxes):
+        """Reference :227-240: detections of ``forward`` go to the COCO-protocol mAP accumulator, the loss is the
+        training loss on the same inputs."""
+        _, scores, pred_classes, pred_boxes = self.forward(inputs)
+        self.map_computer.update(
+            [{"scores": s, "labels": c, "boxes": b} for s, c, b in zip(scores, pred_classes, pred_boxes)],
+            [{"labels": c, "boxes": b} for c, b in zip(classes, boxes)])
         loss, metrics = self.training_step(inputs, classes, boxes, is_validating=True)
         self._val_losses.append(loss.detach())
         return loss, metrics
 
     def on_validation_end(self) -> Dict[str, float]:
-        # box mAP needs a COCO evaluator (torchmetrics + faster_coco_eval in the reference): out of scope
-        return {"loss": torch.stack(self._val_losses).mean().item() if self._val_losses else float("nan")}
+        metrics = self.map_computer.compute() if hasattr(self, "map_computer") else {}
+        metrics["loss"] = torch.stack(self._val_losses).mean().item() if self._val_losses else float("nan")
+        return metrics

@@ -1,0 +1,132 @@
+"""COCO-protocol mean average precision for boxes (the metric the reference's ObjectDetection validation reports through
+torchmetrics' MeanAveragePrecision with the faster_coco_eval backend, src/sihl/heads/object_detection.py:219-250).
+
+Neither torchmetrics nor a COCO evaluator is available offline, so the published COCO detection-evaluation protocol is
+restated here (host-side numpy; validation is not on the hot path): IoU thresholds 0.50:0.05:0.95, greedy matching of
+score-sorted detections to the best still-unmatched ground truth of the same class and image, 101-point interpolated
+precision, area ranges all / small (< 32^2) / medium / large (>= 96^2), maxDets from ``max_detection_thresholds``.
+"parity unpinned": there is no reference output to compare with here; tests/test_host_cpu.py checks hand-computed cases.
+"""
+from typing import Dict, List, Sequence
+
+import numpy as np
+import torch
+
+IOU_THRESHOLDS = np.linspace(0.5, 0.95, 10)
+RECALL_THRESHOLDS = np.linspace(0.0, 1.0, 101)
+AREA_RANGES = {"all": (0.0, 1e10), "small": (0.0, 32.0 ** 2), "medium": (32.0 ** 2, 96.0 ** 2), "large": (96.0 ** 2, 1e10)}
+
+
+def _iou_matrix(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """(n, 4) x (m, 4) xyxy boxes -> (n, m) IoU."""
+    if len(a) == 0 or len(b) == 0:
+        return np.zeros((len(a), len(b)))
+    lt = np.maximum(a[:, None, :2], b[None, :, :2])
+    rb = np.minimum(a[:, None, 2:], b[None, :, 2:])
+    inter = np.clip(rb - lt, 0, None).prod(-1)
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    return inter / np.maximum(area_a[:, None] + area_b[None, :] - inter, 1e-12)
+
+
+class BoxMeanAveragePrecision:
+    def __init__(self, max_detection_thresholds: Sequence[int] = (1, 10, 100)) -> None:
+        self.max_dets = sorted(int(m) for m in max_detection_thresholds)
+        self.reset()
+
+    def reset(self) -> None:
+        self._images: List[Dict[str, np.ndarray]] = []
+
+    def update(self, preds: List[Dict[str, torch.Tensor]], targets: List[Dict[str, torch.Tensor]]) -> None:
+        """preds: per image {"scores" (n,), "labels" (n,), "boxes" (n, 4)}; targets: {"labels" (g,), "boxes" (g, 4)}."""
+        def np_(t):
+            return t.detach().float().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t, dtype=np.float64)
+        for p, t in zip(preds, targets):
+            self._images.append({"scores": np_(p["scores"]).reshape(-1), "labels": np_(p["labels"]).reshape(-1).astype(np.int64),
+                                 "boxes": np_(p["boxes"]).reshape(-1, 4), "gt_labels": np_(t["labels"]).reshape(-1).astype(np.int64),
+                                 "gt_boxes": np_(t["boxes"]).reshape(-1, 4)})
+
+    # ------------------------------------------------------------------ COCO evaluate + accumulate
+    def _evaluate_image(self, img, cls: int, area, max_det: int):
+        gt = img["gt_boxes"][img["gt_labels"] == cls]
+        sel = img["labels"] == cls
+        det, score = img["boxes"][sel], img["scores"][sel]
+        order = np.argsort(-score, kind="mergesort")[:max_det]
+        det, score = det[order], score[order]
+        g_area = (gt[:, 2] - gt[:, 0]) * (gt[:, 3] - gt[:, 1]) if len(gt) else np.zeros(0)
+        g_ignore = (g_area < area[0]) | (g_area > area[1])
+        g_order = np.argsort(g_ignore, kind="mergesort")  # evaluated ground truths first
+        gt, g_ignore = gt[g_order], g_ignore[g_order]
+        ious = _iou_matrix(det, gt)
+        T, D, G = len(IOU_THRESHOLDS), len(det), len(gt)
+        d_match = np.zeros((T, D), dtype=bool)
+        d_ignore = np.zeros((T, D), dtype=bool)
+        for ti, thr in enumerate(IOU_THRESHOLDS):
+            g_taken = np.zeros(G, dtype=bool)
+            for di in range(D):
+                best, m = min(thr, 1 - 1e-10), -1
+                for gi in range(G):
+                    if g_taken[gi]:
+                        continue
+                    if m > -1 and not g_ignore[m] and g_ignore[gi]:
+                        break  # already matched to an evaluated ground truth: do not trade it for an ignored one
+                    if ious[di, gi] < best:
+                        continue
+                    best, m = ious[di, gi], gi
+                if m > -1:
+                    g_taken[m] = True
+                    d_match[ti, di] = True
+                    d_ignore[ti, di] = g_ignore[m]
+        d_area = (det[:, 2] - det[:, 0]) * (det[:, 3] - det[:, 1]) if D else np.zeros(0)
+        outside = (d_area < area[0]) | (d_area > area[1])
+        d_ignore = d_ignore | (~d_match & outside[None, :])  # unmatched detections outside the range do not count
+        return score, d_match, d_ignore, int((~g_ignore).sum())
+
+    def _accumulate(self, area_name: str, max_det: int):
+        classes = sorted({int(c) for img in self._images for c in np.concatenate([img["labels"], img["gt_labels"]])})
+        T, R = len(IOU_THRESHOLDS), len(RECALL_THRESHOLDS)
+        precision = -np.ones((T, R, len(classes)))
+        recall = -np.ones((T, len(classes)))
+        for ci, cls in enumerate(classes):
+            evals = [self._evaluate_image(img, cls, AREA_RANGES[area_name], max_det) for img in self._images]
+            n_gt = sum(e[3] for e in evals)
+            if n_gt == 0:
+                continue
+            scores = np.concatenate([e[0] for e in evals])
+            order = np.argsort(-scores, kind="mergesort")
+            match = np.concatenate([e[1] for e in evals], axis=1)[:, order]
+            ignore = np.concatenate([e[2] for e in evals], axis=1)[:, order]
+            tps = np.cumsum(match & ~ignore, axis=1).astype(np.float64)
+            fps = np.cumsum(~match & ~ignore, axis=1).astype(np.float64)
+            for ti in range(T):
+                tp, fp = tps[ti], fps[ti]
+                rc = tp / n_gt
+                pr = tp / np.maximum(tp + fp, np.spacing(1))
+                recall[ti, ci] = rc[-1] if len(rc) else 0.0
+                for i in range(len(pr) - 1, 0, -1):  # precision envelope
+                    pr[i - 1] = max(pr[i - 1], pr[i])
+                idx = np.searchsorted(rc, RECALL_THRESHOLDS, side="left")
+                q = np.zeros(R)
+                ok = idx < len(pr)
+                q[ok] = pr[idx[ok]]
+                precision[ti, :, ci] = q
+        return precision, recall
+
+    def compute(self) -> Dict[str, float]:
+        def mean_valid(x):
+            x = x[x > -1]
+            return float(x.mean()) if x.size else -1.0
+        out: Dict[str, float] = {}
+        top = self.max_dets[-1]
+        p_all, _ = self._accumulate("all", top)
+        out["map"] = mean_valid(p_all)
+        out["map_50"] = mean_valid(p_all[0])
+        out["map_75"] = mean_valid(p_all[5])
+        for name in ("small", "medium", "large"):
+            p, r = self._accumulate(name, top)
+            out[f"map_{name}"] = mean_valid(p)
+            out[f"mar_{name}"] = mean_valid(r)
+        for m in self.max_dets:
+            _, r = self._accumulate("all", m)
+            out[f"mar_{m}"] = mean_valid(r)
+        return out

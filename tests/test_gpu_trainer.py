@@ -93,3 +93,19 @@ def test_graph_step_follows_lr_schedule():
         assert moved == (step >= 4), (step, moved)
     for a, b in zip(ref_model.parameters(), graph_model.parameters()):
         assert float((a - b).abs().max()) <= 3 * LR
+
+
+def test_object_detection_validation_reports_coco_map():
+    """validation_step / on_validation_end of the HIP head (reference :219-250): loss + COCO-protocol box mAP keys."""
+    model = _model().eval()
+    head = model.heads[0]
+    head.on_validation_start()
+    with torch.no_grad():
+        for seed in range(2):
+            images, targets = _batch(seed, (2, 0, 3))
+            loss, _ = head.validation_step(model.extract_features(images), **targets[0])
+            assert torch.isfinite(loss)
+    metrics = head.on_validation_end()
+    for key in ("map", "map_50", "map_75", "mar_1", "mar_10", "mar_100", "loss"):
+        assert key in metrics
+    assert 0.0 <= metrics["map"] <= 1.0 and metrics["loss"] > 0

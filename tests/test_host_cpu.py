@@ -179,3 +179,29 @@ def test_trainer_warmup_schedule_matches_reference_recipe():
     for lrs, f in zip(seen, factors):
         for lr, b in zip(lrs, base):
             assert abs(lr - b * f) < 1e-9 * max(1.0, b), (lrs, f)
+
+
+def test_box_map_matches_hand_computed_coco_protocol():
+    """COCO-protocol box mAP (sihl_amd/metrics.py): perfect detections score 1; one class with two ground truths and
+    detections TP(0.9) FP(0.8) TP(0.7) has the precision envelope 1.0 up to recall 0.5 and 2/3 beyond - (51 + 50*2/3)/101
+    with 101-point interpolation; a detection overlapping at IoU 0.6 counts for thresholds 0.50-0.60 only."""
+    from sihl_amd.metrics import BoxMeanAveragePrecision
+    m = BoxMeanAveragePrecision((1, 10, 100))
+    gt = [{"labels": torch.tensor([0, 1]), "boxes": torch.tensor([[10.0, 10, 50, 50], [60, 60, 200, 200]])}]
+    m.update([{"scores": torch.tensor([0.9, 0.8]), "labels": torch.tensor([0, 1]), "boxes": gt[0]["boxes"].clone()}], gt)
+    r = m.compute()
+    assert r["map"] == 1.0 and r["map_50"] == 1.0 and r["mar_100"] == 1.0 and r["map_small"] == -1.0
+    m.reset()
+    gt = [{"labels": torch.tensor([0, 0]), "boxes": torch.tensor([[0.0, 0, 100, 100], [200, 200, 300, 300]])}]
+    pred = [{"scores": torch.tensor([0.9, 0.8, 0.7]), "labels": torch.tensor([0, 0, 0]),
+             "boxes": torch.tensor([[0.0, 0, 100, 100], [400, 400, 500, 500], [200, 200, 300, 300]])}]
+    m.update(pred, gt)
+    r = m.compute()
+    want = (51 + 50 * 2 / 3) / 101
+    assert abs(r["map"] - want) < 1e-9 and abs(r["map_50"] - want) < 1e-9
+    assert r["mar_1"] == 0.5 and r["mar_10"] == 1.0
+    m.reset()
+    gt = [{"labels": torch.tensor([0]), "boxes": torch.tensor([[0.0, 0, 100, 100]])}]
+    m.update([{"scores": torch.tensor([0.5]), "labels": torch.tensor([0]), "boxes": torch.tensor([[0.0, 0, 100, 60]])}], gt)
+    r = m.compute()  # IoU 0.6: true positive at 0.50, 0.55, 0.60 -> 3 of 10 thresholds
+    assert abs(r["map"] - 0.3) < 1e-9 and r["map_50"] == 1.0 and r["map_75"] == 0.0
