@@ -200,6 +200,19 @@ def main():
     nw, msw, flw, byw = ctypes.c_long(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
     lib.sihl_profile_collect(1, dt_code, ctypes.byref(nw), ctypes.byref(msw), ctypes.byref(flw), ctypes.byref(byw))
     peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+
+    def per_launch_roofline(slot):
+        """sum over launches of max(flops / MFMA peak, algorithmic bytes / HBM peak) divided by the measured time: the
+        thin ResNet layers are HBM-bound even at the matrix-core kernel (AI 50-200 flop/B against a ridge of ~310)."""
+        cnt = lib.sihl_profile_records(slot, dt_code, None, 0)
+        if cnt <= 0:
+            return None
+        buf = (ctypes.c_double * (3 * cnt))()
+        lib.sihl_profile_records(slot, dt_code, buf, cnt)
+        ideal = sum(max(buf[3 * i + 1] / (peak * 1e12), buf[3 * i + 2] / 8e12) for i in range(cnt))
+        spent = sum(buf[3 * i] for i in range(cnt)) * 1e-3
+        return ideal / spent if spent > 0 else None
+
     roofline = None
     # HBM traffic of the conv kernel per launch: PMC counters need their own rocprofv3 passes (FETCH_SIZE, WRITE_SIZE;
     # profiles/pmc_summarize.py applies the gfx950 correction), so the figure comes from the committed summary of
@@ -218,12 +231,14 @@ def main():
                     "traffic_note": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_bench.json); "
                                     "algorithmic bytes per launch: avg_algorithmic_mb_per_launch",
                     "avg_algorithmic_mb_per_launch": by.value / n.value / 1e6,
+                    "frac_of_per_launch_roofline": per_launch_roofline(0),  # each launch against min(MFMA, HBM) bound
                     "launches_per_step": n.value / profiled_steps, "avg_launch_us": ms.value * 1e3 / n.value,
                     "avg_gflop_per_launch": fl.value / n.value / 1e9,
                     "kernel_ms_per_step": ms.value / profiled_steps,
                     "measured_over": f"{profiled_steps} eager steps of the same workload right after the timed region "
                                      "(timing events cost ~5 % of a step and cannot ride in a graph replay)",
                     "wgrad": {"achieved": (flw.value / (msw.value * 1e-3) / 1e12) if nw.value else None,
+                              "frac_of_per_launch_roofline": per_launch_roofline(1),
                               "launches_per_step": nw.value / profiled_steps,
                               "kernel_ms_per_step": msw.value / profiled_steps}}
 
