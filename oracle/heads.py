@@ -8,6 +8,7 @@ TEST INFRASTRUCTURE ONLY.  Reference files followed (relative to
   heads/multiclass_classification.py:47-52   MulticlassClassification (config-1 plumbing)
   heads/instance_segmentation.py:15-278      InstanceSegmentation (CondInst mask decode)
   heads/depth_estimation.py:15-122           DepthEstimation (AdaBins on the SemanticSegmentation decoder; 8f rank 4)
+  heads/keypoint_detection.py:15-322,342-378 KeypointDetection (FCPose dynamic heatmaps; 8f rank 4)
 torchvision 0.21 ``ops.complete_box_iou`` / ``complete_box_iou_loss`` are NOT in
 the container; they are restated from the published CIoU definition (SURVEY.md
 App. B) and are "parity unpinned".
@@ -371,6 +372,162 @@ class InstanceSegmentation(nn.Module):
         cls_loss = (wts * cls_loss).sum() / wts.sum()
         loss = loc_loss + 10 * mask_loss + cls_loss
         return loss, {"location_loss": loc_loss, "mask_loss": mask_loss, "class_loss": cls_loss}
+
+
+# --------------------------------------------------------------------------- keypoint detection (FCPose)
+def dynamic_keypoint_net(feats: Tensor, weights: Tensor, c: int, k: int) -> Tensor:
+    """feats (n, c+2, h, w), weights (n, (c+2)c + c + cc + c + ck + k) -> heatmap logits (n, k, h, w)
+    (keypoint_detection.py:139-158 / 276-288)."""
+    n = weights.shape[0]
+    i = 0
+    w1 = weights[:, i: (i := i + (c + 2) * c)].reshape(n, c + 2, c)
+    b1 = weights[:, i: (i := i + c)].reshape(n, c, 1, 1)
+    w2 = weights[:, i: (i := i + c * c)].reshape(n, c, c)
+    b2 = weights[:, i: (i := i + c)].reshape(n, c, 1, 1)
+    w3 = weights[:, i: (i := i + c * k)].reshape(n, c, k)
+    b3 = weights[:, i:].reshape(n, k, 1, 1)
+    x = F.silu(torch.einsum("nchw,ncd->ndhw", feats, w1) + b1)
+    x = F.silu(torch.einsum("nchw,ncd->ndhw", x, w2) + b2)
+    return torch.einsum("nchw,ncd->ndhw", x, w3) + b3
+
+
+def keypoints_to_boxes(keypoints: Tensor, presence: Tensor) -> Tensor:
+    """(n, k, 2) keypoints, (n, k) bool presence -> (n, 4) xyxy hull of the present keypoints (:342-353)."""
+    lo = keypoints.masked_fill(~presence[..., None], float("inf")).amin(dim=1)
+    hi = keypoints.masked_fill(~presence[..., None], float("-inf")).amax(dim=1)
+    return torch.cat([lo, hi], dim=-1)
+
+
+def keypoints_to_heatmaps(keypoints: Tensor, presence: Tensor, height: int, width: int, img_height: int,
+                          img_width: int) -> Tensor:
+    """One-hot (n, k, height, width) targets at the rounded, rescaled keypoint cell; all-zero where absent (:355-378)."""
+    xs = (keypoints[:, :, 0] * ((width - 1) / (img_width - 1))).clamp(0, width - 1).round().to(torch.int64)
+    ys = (keypoints[:, :, 1] * ((height - 1) / (img_height - 1))).clamp(0, height - 1).round().to(torch.int64)
+    gx = F.one_hot(xs, width).to(torch.float32)
+    gy = F.one_hot(ys, height).to(torch.float32)
+    return presence[:, :, None, None] * gx.unsqueeze(2) * gy.unsqueeze(3)
+
+
+class KeypointDetection(nn.Module):
+    """Instance-aware keypoint heatmaps: the detector front end + a kernel MLP emitting a per-instance 3-layer 1x1
+    network (c+2 -> c -> c -> num_keypoints, c = 32) run over the mask-level features + relative coordinates."""
+
+    def __init__(self, in_channels: List[int], num_keypoints: int, mask_level: int = 3, bottom_level: int = 5,
+                 top_level: int = 5, num_channels: int = 256, num_layers: int = 4, max_instances: int = 100):
+        assert num_keypoints > 0 and len(in_channels) > top_level
+        assert 0 < bottom_level <= top_level and num_channels % 4 == 0
+        assert num_layers >= 0 and max_instances > 0
+        super().__init__()
+        self.in_channels, self.num_keypoints, self.mask_level = in_channels, num_keypoints, mask_level
+        self.bottom_level, self.top_level = bottom_level, top_level
+        self.levels = range(bottom_level, top_level + 1)
+        self.num_channels, self.num_layers = num_channels, num_layers
+        self.max_instances, self.topk = max_instances, 9
+        self.laterals = nn.ModuleList([
+            Conv2dNormActivation(in_channels[l], num_channels, 1, activation_layer=None) for l in self.levels])
+        hidden = [num_channels] * num_layers
+
+        def mlp(out):
+            return MLP(num_channels, hidden + [out], norm_layer=nn.LayerNorm, activation_layer=nn.SiLU)
+
+        self.loc_head = mlp(1)
+        self.loc_head[-2].bias.data.fill_(-5.0)
+        self.presence_head = mlp(num_keypoints)
+        c = self.mask_num_channels = 32
+        self.kernel_head = mlp((c + 2) * c + c + c * c + c + c * num_keypoints + num_keypoints)
+        self.mask_lateral = Conv2dNormActivation(in_channels[mask_level], num_channels, 1, activation_layer=None)
+        self.mask_head = Conv2dNormActivation(num_channels, c, 3, activation_layer=nn.SiLU)
+        self.output_shapes = {"num_instances": ("batch_size",), "scores": ("batch_size", max_instances),
+                              "presence": ("batch_size", max_instances, num_keypoints),
+                              "keypoints": ("batch_size", max_instances, num_keypoints, 2)}
+
+    keypoints_to_boxes = staticmethod(keypoints_to_boxes)
+    keypoints_to_heatmaps = staticmethod(keypoints_to_heatmaps)
+
+    def _flat_feats(self, inputs: List[Tensor]) -> Tensor:
+        feats = [lat(inputs[l]) for l, lat in zip(self.levels, self.laterals)]
+        return torch.cat([f.flatten(2).transpose(1, 2) for f in feats], dim=1)
+
+    def _sizes(self, inputs: List[Tensor]) -> List[Tuple[int, int]]:
+        return [tuple(inputs[l].shape[2:]) for l in self.levels]
+
+    def forward(self, inputs: List[Tensor], output_heatmaps: bool = False):
+        B, _, H, W = inputs[0].shape
+        K, c, dev = self.max_instances, self.mask_num_channels, inputs[0].device
+        flat = self._flat_feats(inputs)
+        loc_logits, idx = self.loc_head(flat).squeeze(2).topk(K, dim=1)
+        rows = torch.arange(B)[:, None].expand(B, K)
+        scores = loc_logits.sigmoid()
+        num_instances = (scores > 0.5).sum(dim=1)
+        sel = flat[rows, idx]
+        mask_feats = self.mask_head(self.mask_lateral(inputs[self.mask_level]))
+        h, w = mask_feats.shape[2:]
+        offsets = torch.cat([g.reshape(-1, 2) for g in grid_offsets(self._sizes(inputs), dev)])[idx]
+        grid = grid_offsets([(h, w)], dev)[0].permute(2, 0, 1)
+        rel = grid[None, None] - offsets[:, :, :, None, None]
+        feats = torch.cat([mask_feats[:, None].expand(B, K, c, h, w), rel], dim=2).reshape(B * K, c + 2, h, w)
+        heat = dynamic_keypoint_net(feats, self.kernel_head(sel).reshape(B * K, -1), c, self.num_keypoints)
+        heat = heat.reshape(B, K, self.num_keypoints, h, w)
+        presence = self.presence_head(sel).sigmoid()
+        if output_heatmaps:
+            return heat.flatten(3, 4).softmax(3).reshape(heat.shape)
+        flat_idx = heat.flatten(3, 4).max(3).indices
+        ky, kx = flat_idx // h, flat_idx % h  # the reference divides by the mask HEIGHT for both (:165)
+        ky = (ky.float() + 0.5) / h * H
+        kx = (kx.float() + 0.5) / w * W
+        return num_instances, scores, presence, torch.stack([kx, ky], dim=3)
+
+    def training_step(self, inputs: List[Tensor], presence: List[Tensor], keypoints: List[Tensor],
+                      is_validating: bool = False):
+        assert len(inputs) > self.top_level
+        dev = inputs[0].device
+        B, _, H, W = inputs[0].shape
+        c, nk = self.mask_num_channels, self.num_keypoints
+        keep = [p.any(dim=1) for p in presence]  # instances without any visible keypoint are dropped (:186-192)
+        keypoints = [k[m] for k, m in zip(keypoints, keep)]
+        presence = [p[m] for p, m in zip(presence, keep)]
+        boxes = [keypoints_to_boxes(k, p) for k, p in zip(keypoints, presence)]
+        centres = torch.cat([g.reshape(-1, 2) for g in grid_offsets(self._sizes(inputs), dev)])
+        half = torch.cat([torch.tensor([-0.5 / w_, -0.5 / h_, 0.5 / w_, 0.5 / h_], device=dev).expand(h_ * w_, 4)
+                          for h_, w_ in self._sizes(inputs)])
+        anchors = (centres.repeat(1, 2) + half) * torch.tensor([[W, H, W, H]], device=dev)
+        matches = [bbox_matching(anchors, boxes[b], self.topk, relative=True) for b in range(B)]
+        assignment = torch.stack([m[0] for m in matches])
+        rel_iou = torch.stack([m[1] for m in matches])
+        flat = self._flat_feats(inputs)
+        o2m = rel_iou > 0
+        wts = rel_iou[o2m].reshape(-1, 1)
+        sel = flat[o2m]
+        loc_logits = self.loc_head(flat).squeeze(2)
+        loc_target = (rel_iou == 1.0).to(torch.float32)
+        loc_loss = F.binary_cross_entropy_with_logits(loc_logits.float(), loc_target, reduction="none")
+        loc_loss = loc_loss.sum() / loc_target.sum()
+        z = torch.zeros_like(loc_loss)
+        if rel_iou.max() == 0:
+            return loc_loss, {"location_loss": loc_loss, "keypoint_loss": z, "presence_loss": z}
+
+        target_presence = torch.cat([presence[b][assignment[b, o2m[b]]] for b in range(B)])
+        presence_loss = F.binary_cross_entropy_with_logits(self.presence_head(sel).float(),
+                                                           target_presence.to(torch.float32), reduction="none")
+        presence_loss = (wts * presence_loss).sum() / wts.sum()
+
+        mask_feats = self.mask_head(self.mask_lateral(inputs[self.mask_level]))
+        h, w = mask_feats.shape[2:]
+        grid = grid_offsets([(h, w)], dev)[0].permute(2, 0, 1)
+        per_image = []
+        for b in range(B):
+            idx = o2m[b].nonzero()[:, 0]
+            if idx.numel():
+                rel = grid[None] - centres[idx][:, :, None, None]
+                per_image.append(torch.cat([mask_feats[b][None].expand(idx.numel(), c, h, w), rel], dim=1))
+        heat = dynamic_keypoint_net(torch.cat(per_image), self.kernel_head(sel), c, nk)
+        target_kpts = torch.cat([keypoints[b][assignment[b, o2m[b]]] for b in range(B)])
+        target_heat = keypoints_to_heatmaps(target_kpts, target_presence, h, w, H, W)
+        kp_loss = F.cross_entropy(heat.flatten(2).transpose(1, 2).float(), target_heat.flatten(2).transpose(1, 2),
+                                  reduction="none")  # classes = the h*w cells, "spatial" dim = keypoints
+        kp_loss = (wts * kp_loss).sum() / wts.sum()
+        loss = loc_loss + kp_loss + presence_loss
+        return loss, {"location_loss": loc_loss, "keypoint_loss": kp_loss, "presence_loss": presence_loss}
 
 
 # --------------------------------------------------------------------------- SemSeg head

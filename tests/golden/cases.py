@@ -440,3 +440,50 @@ _neck("hybrid_3to6_train", lambda ns: perturb_(ns.HybridEncoder(list(_HE_CH), 32
       _HE_CH, 128, range(3, 6), 2, True, 121, [3, 4, 5, 6])
 for c in ("hybrid_3to6_eval", "hybrid_3to6_train"):
     CASES[c].needs = "hybrid"
+
+
+# ------------------------------------------------------------------ keypoint-detection head
+def _kp_build(ns):
+    return perturb_(ns.KeypointDetection(_IS_CH, num_keypoints=5, mask_level=3, bottom_level=4, top_level=5,
+                                         num_channels=32, num_layers=2, max_instances=6), 27, scale=0.6)
+
+
+def _kp_forward_run(m, inp):
+    with torch.no_grad():
+        n, scores, presence, kpts = m(inp["levels"])
+        heat = m(inp["levels"], output_heatmaps=True)
+    return {"num_instances": n, "scores": scores, "presence": presence, "keypoints": kpts, "heatmaps": heat}
+
+
+_register("kpt_forward_eval", _kp_build, _is_inputs, _kp_forward_run, False, needs="kpt")
+
+
+def kpt_targets():
+    """2 images: two persons (one of them without any visible keypoint, dropped by the head) and one person."""
+    k0 = torch.tensor([[[10.0, 12], [30, 14], [22, 40], [12, 50], [34, 52]],
+                       [[1.0, 1], [2, 2], [3, 3], [4, 4], [5, 5]],
+                       [[40.0, 8], [58, 10], [50, 30], [42, 44], [60, 46]]])
+    p0 = torch.tensor([[True, True, False, True, True], [False] * 5, [True, True, True, True, False]])
+    k1 = torch.tensor([[[20.0, 20], [44, 22], [32, 36], [24, 56], [46, 58]]])
+    p1 = torch.tensor([[True, False, True, True, True]])
+    return [p0, p1], [k0, k1]
+
+
+def _kp_train_run(m, inp):
+    lv = [t.clone().requires_grad_(i >= 3) for i, t in enumerate(inp["levels"])]
+    dev = lv[3].device
+    presence, keypoints = kpt_targets()
+    loss, metrics = m.training_step(lv, [p.to(dev) for p in presence], [k.to(dev) for k in keypoints])
+    res = {"loss": loss, **{k: v for k, v in metrics.items()}}
+    params = [(n, p) for n, p in m.named_parameters()]
+    g = torch.autograd.grad(loss, lv[3:] + [p for _, p in params], allow_unused=True)
+    for i, gi in enumerate(g[:3]):
+        if gi is not None:
+            res[f"gin{i}"] = gi
+    for (n, _), gp in zip(params, g[3:]):
+        if gp is not None:
+            res[f"gp.{n}"] = gp
+    return res
+
+
+_register("kpt_training_step", _kp_build, _is_inputs, _kp_train_run, True, needs="kpt")

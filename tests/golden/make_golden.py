@@ -12,7 +12,8 @@ package objects are registered for ``sihl``, ``sihl.layers`` and ``sihl.heads``
 and each hot-path file is executed with importlib from where it lies:
   layers/{convblocks,pooling,scalers,bifpn}.py  - need only torch/einops/numpy: run UNMODIFIED
   layers/fpn.py, layers/hybrid_encoder.py, utils/__init__.py (+ polygon_iou, pck, f1), heads/object_detection.py,
-  heads/semantic_segmentation.py, heads/instance_segmentation.py, heads/depth_estimation.py
+  heads/semantic_segmentation.py, heads/instance_segmentation.py, heads/depth_estimation.py,
+  heads/keypoint_detection.py
       - additionally import ``torchvision.ops`` / ``torchmetrics``.  Stand-in modules are
         registered for those imports: ``ops.Conv2dNormActivation`` / ``ops.MLP`` (compositions
         of torch.nn layers, documented structure) and ``ops.complete_box_iou[_loss]`` (published
@@ -104,7 +105,8 @@ def load_reference():
     tmr = types.ModuleType("torchmetrics.regression")
     tmr.MeanAbsoluteError, tmr.MeanSquaredError = type("MeanAbsoluteError", (), {}), type("MeanSquaredError", (), {})
     sys.modules["torchmetrics.regression"] = tmr
-    for name in ("object_detection", "semantic_segmentation", "instance_segmentation", "depth_estimation"):
+    for name in ("object_detection", "semantic_segmentation", "instance_segmentation", "depth_estimation",
+                 "keypoint_detection"):
         mod = _load(f"sihl.heads.{name}", f"heads/{name}.py")
         for k, v in vars(mod).items():
             if isinstance(v, type) and v.__module__ == mod.__name__:
@@ -123,7 +125,7 @@ def _flatten(prefix, obj, out):
 
 
 PINNED = {"layers": "reference-unmodified", "fpn": "reference+tv-standins",
-          "od": "reference+tv-standins", "semseg": "reference+tv-standins", "iseg": "reference+tv-standins", "depth": "reference+tv-standins", "hybrid": "reference+tv-standins"}
+          "od": "reference+tv-standins", "semseg": "reference+tv-standins", "iseg": "reference+tv-standins", "depth": "reference+tv-standins", "hybrid": "reference+tv-standins", "kpt": "reference+tv-standins"}
 
 
 def main(argv):
