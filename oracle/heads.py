@@ -9,6 +9,8 @@ TEST INFRASTRUCTURE ONLY.  Reference files followed (relative to
   heads/instance_segmentation.py:15-278      InstanceSegmentation (CondInst mask decode)
   heads/depth_estimation.py:15-122           DepthEstimation (AdaBins on the SemanticSegmentation decoder; 8f rank 4)
   heads/keypoint_detection.py:15-322,342-378 KeypointDetection (FCPose dynamic heatmaps; 8f rank 4)
+  heads/quadrilateral_detection.py:13-211,258-324  QuadrilateralDetection (8f rank 4); torchvision's
+                                             sigmoid_focal_loss restated from its published definition (unpinned)
 torchvision 0.21 ``ops.complete_box_iou`` / ``complete_box_iou_loss`` are NOT in
 the container; they are restated from the published CIoU definition (SURVEY.md
 App. B) and are "parity unpinned".
@@ -528,6 +530,150 @@ class KeypointDetection(nn.Module):
         kp_loss = (wts * kp_loss).sum() / wts.sum()
         loss = loc_loss + kp_loss + presence_loss
         return loss, {"location_loss": loc_loss, "keypoint_loss": kp_loss, "presence_loss": presence_loss}
+
+
+# --------------------------------------------------------------------------- quadrilateral detection
+def sigmoid_focal_loss(logits: Tensor, targets: Tensor, alpha: float = 0.25, gamma: float = 2.0) -> Tensor:
+    """torchvision.ops.sigmoid_focal_loss(reduction="none"): RetinaNet focal loss on logits."""
+    p = torch.sigmoid(logits)
+    ce = F.binary_cross_entropy_with_logits(logits, targets, reduction="none")
+    p_t = p * targets + (1 - p) * (1 - targets)
+    loss = ce * (1 - p_t) ** gamma
+    return (alpha * targets + (1 - alpha) * (1 - targets)) * loss
+
+
+def quad_bbox_matching(anchors: Tensor, gt_boxes: Tensor, topk: int):
+    """Top-k-per-GT assignment without the clamp of the box detector, plus the one-to-one (best anchor per GT) mask
+    (quadrilateral_detection.py:258-289)."""
+    A, G = anchors.shape[0], gt_boxes.shape[0]
+    dev = anchors.device
+    assign = torch.full((A,), -1, device=dev)
+    o2o = torch.zeros((A,), dtype=torch.bool, device=dev)
+    iou_out, rel = torch.zeros((A,), device=dev), torch.zeros((A,), device=dev)
+    if G == 0:
+        return assign, o2o, iou_out, rel
+    ious = complete_box_iou(anchors, gt_boxes)
+    top_v, top_i = torch.topk(ious, k=topk, dim=0)
+    best = torch.zeros((A, G), dtype=torch.bool, device=dev).scatter_(0, top_i[0:1], True)
+    in_topk = torch.zeros((A, G), dtype=torch.bool, device=dev).scatter_(0, top_i, True)
+    max_iou, max_gt = torch.max(ious * in_topk.float(), dim=1)
+    valid = in_topk.any(dim=1)
+    assign = torch.where(valid, max_gt, assign)
+    iou_out = torch.where(valid, max_iou, iou_out)
+    rel = torch.where(valid, (max_iou / top_v[0][max_gt]).nan_to_num(0), rel)
+    return assign, best.any(dim=1), iou_out, rel
+
+
+def canonicalize_and_convexify(quads: Tensor) -> Tensor:
+    """Vertices sorted by angle around the centroid; concave vertices replaced by the midpoint of their neighbours
+    (quadrilateral_detection.py:291-313)."""
+    rel = quads - quads.mean(dim=1, keepdim=True)
+    order = torch.atan2(rel[..., 1], rel[..., 0]).sort(dim=1).indices
+    v = torch.gather(quads, 1, order[..., None].expand(-1, -1, 2))
+    nxt, prv = v[:, [1, 2, 3, 0]], v[:, [3, 0, 1, 2]]
+    cross = (nxt[..., 0] - v[..., 0]) * (prv[..., 1] - v[..., 1]) - (nxt[..., 1] - v[..., 1]) * (prv[..., 0] - v[..., 0])
+    return torch.where((cross < 0)[..., None], (prv + nxt) * 0.5, v)
+
+
+def quads_to_boxes(quads: Tensor) -> Tensor:
+    x, y = quads[..., 0], quads[..., 1]
+    return torch.stack([x.min(-1).values, y.min(-1).values, x.max(-1).values, y.max(-1).values], 1)
+
+
+class QuadrilateralDetection(nn.Module):
+    """Detector skeleton with conv+BN+SiLU laterals plus a global-context vector (1x1 conv+BN+SiLU of the top level,
+    globally averaged) added to every position; quads = cell centre + tanh(MLP) per vertex."""
+
+    def __init__(self, in_channels: List[int], num_classes: int, bottom_level: int = 3, top_level: int = 5,
+                 num_channels: int = 256, num_layers: int = 4, max_instances: int = 100):
+        assert num_classes > 0 and len(in_channels) > top_level
+        assert 0 < bottom_level <= top_level and num_channels % 4 == 0
+        assert num_layers >= 0 and max_instances > 0
+        super().__init__()
+        self.in_channels, self.num_classes = in_channels, num_classes
+        self.bottom_level, self.top_level = bottom_level, top_level
+        self.levels = range(bottom_level, top_level + 1)
+        self.num_channels, self.num_layers = num_channels, num_layers
+        self.max_instances, self.topk = max_instances, 9
+        self.laterals = nn.ModuleList([
+            Conv2dNormActivation(in_channels[l], num_channels, 1, activation_layer=nn.SiLU) for l in self.levels])
+        self.global_context = nn.Sequential(
+            Conv2dNormActivation(in_channels[top_level], num_channels, 1, activation_layer=nn.SiLU),
+            nn.AdaptiveAvgPool2d(1))
+        hidden = [num_channels] * num_layers
+
+        def mlp(out):
+            return MLP(num_channels, hidden + [out], norm_layer=nn.LayerNorm, activation_layer=nn.SiLU)
+
+        self.loc_head, self.class_head, self.quad_head = mlp(1), mlp(num_classes), mlp(8)
+        self.output_shapes = {"num_instances": ("batch_size",), "scores": ("batch_size", max_instances),
+                              "classes": ("batch_size", max_instances), "quads": ("batch_size", max_instances, 4, 2)}
+
+    bbox_matching = staticmethod(quad_bbox_matching)
+    canonicalize_and_convexify = staticmethod(canonicalize_and_convexify)
+    quads_to_boxes = staticmethod(quads_to_boxes)
+
+    def _sizes(self, inputs: List[Tensor]) -> List[Tuple[int, int]]:
+        return [tuple(inputs[l].shape[2:]) for l in self.levels]
+
+    def get_offsets_and_levels(self, inputs: List[Tensor]) -> Tuple[Tensor, Tensor]:
+        dev = inputs[0].device
+        centres = torch.cat([g.reshape(-1, 2) for g in grid_offsets(self._sizes(inputs), dev)])
+        levels = torch.cat([torch.full((h * w, 1), l, device=dev) for l, (h, w) in zip(self.levels, self._sizes(inputs))])
+        return centres.repeat(1, 4), levels
+
+    def _flat_feats(self, inputs: List[Tensor]) -> Tensor:
+        ctx = self.global_context(inputs[self.top_level])
+        feats = [lat(inputs[l]) + ctx for l, lat in zip(self.levels, self.laterals)]
+        return torch.cat([f.flatten(2).transpose(1, 2) for f in feats], dim=1)
+
+    def forward(self, inputs: List[Tensor]):
+        B, _, H, W = inputs[0].shape
+        K = self.max_instances
+        flat = self._flat_feats(inputs)
+        offsets, _ = self.get_offsets_and_levels(inputs)
+        loc_logits, idx = self.loc_head(flat).squeeze(2).topk(K, dim=1)
+        rows = torch.arange(B)[:, None].expand(B, K)
+        scores = loc_logits.sigmoid()
+        num_instances = (scores > 0.5).sum(dim=1)
+        sel = flat[rows, idx]
+        quads = (offsets[idx] + self.quad_head(sel).tanh()) * torch.tensor([[[W, H] * 4]], device=flat.device)
+        classes = self.class_head(sel).max(dim=2).indices
+        return num_instances, scores, classes, quads.reshape(B, K, 4, 2)
+
+    def training_step(self, inputs: List[Tensor], classes: List[Tensor], quads: List[Tensor],
+                      is_validating: bool = False):
+        assert len(inputs) > self.top_level
+        dev = inputs[0].device
+        B, _, H, W = inputs[0].shape
+        flat = self._flat_feats(inputs)
+        offsets, levels = self.get_offsets_and_levels(inputs)
+        scale = torch.sigmoid(levels - self.top_level)
+        anchors = (offsets[:, :4] + torch.tensor([[-1, -1, 1, 1]], device=dev) * scale) * torch.tensor([[W, H] * 2], device=dev)
+        matches = [quad_bbox_matching(anchors, quads_to_boxes(q), self.topk) for q in quads]
+        assignment = torch.stack([m[0] for m in matches])
+        o2o = torch.stack([m[1] for m in matches])
+        rel_iou = torch.stack([m[3] for m in matches])
+        o2m = rel_iou > 0
+        loc_target = rel_iou / self.topk
+        loc_target[o2o] = 1
+        wts = rel_iou[o2m]
+        sel = flat[o2m]
+        off_sel = torch.cat([offsets[m] for m in o2m])
+        quad_preds = (off_sel + self.quad_head(sel).tanh()).clamp(0, 1).reshape(-1, 4, 2)
+        quad_target = torch.cat([quads[b][assignment[b, m]] for b, m in enumerate(o2m)])
+        quad_target = canonicalize_and_convexify(quad_target) / torch.tensor([[[W, H]] * 4], device=dev)
+        quad_loss = F.l1_loss(quad_preds.float(), quad_target, reduction="none").sum(dim=(1, 2))
+        quad_loss = 10 * (wts * quad_loss).sum() / wts.sum()
+        cls_target = torch.cat([classes[b][assignment[b, m]] for b, m in enumerate(o2m)])
+        cls_loss = sigmoid_focal_loss(self.class_head(sel).float(),
+                                      F.one_hot(cls_target, self.num_classes).to(torch.float32)).sum(dim=1)
+        cls_loss = 10 * (wts * cls_loss).sum() / wts.sum()
+        loc_logits = self.loc_head(flat).squeeze(2)
+        loc_loss = F.binary_cross_entropy_with_logits(loc_logits.float(), loc_target, reduction="none")
+        loc_loss = loc_loss.sum() / loc_target.sum()
+        loss = loc_loss + quad_loss + cls_loss
+        return loss, {"location_loss": loc_loss, "quad_loss": quad_loss, "class_loss": cls_loss}
 
 
 # --------------------------------------------------------------------------- SemSeg head

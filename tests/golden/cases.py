@@ -487,3 +487,45 @@ def _kp_train_run(m, inp):
 
 
 _register("kpt_training_step", _kp_build, _is_inputs, _kp_train_run, True, needs="kpt")
+
+
+# ------------------------------------------------------------------ quadrilateral-detection head
+def _quad_build(ns):
+    return perturb_(ns.QuadrilateralDetection(_IS_CH, num_classes=4, bottom_level=3, top_level=5, num_channels=32,
+                                              num_layers=2, max_instances=8), 29, scale=0.6)
+
+
+def _quad_forward_run(m, inp):
+    with torch.no_grad():
+        n, scores, classes, quads = m(inp["levels"])
+    return {"num_instances": n, "scores": scores, "classes": classes, "quads": quads}
+
+
+_register("quad_forward_eval", _quad_build, _is_inputs, _quad_forward_run, False, needs="quad")
+
+
+def quad_targets():
+    """2 images: two quadrilaterals (one given with a concave vertex order) and one."""
+    q0 = torch.tensor([[[8.0, 10], [40, 6], [46, 36], [12, 42]], [[30.0, 30], [58, 34], [44, 44], [56, 60]]])
+    q1 = torch.tensor([[[20.0, 8], [52, 14], [48, 50], [16, 44]]])
+    return [torch.tensor([1, 3]), torch.tensor([0])], [q0, q1]
+
+
+def _quad_train_run(m, inp):
+    lv = [t.clone().requires_grad_(i >= 3) for i, t in enumerate(inp["levels"])]
+    dev = lv[3].device
+    classes, quads = quad_targets()
+    loss, metrics = m.training_step(lv, [c.to(dev) for c in classes], [q.to(dev) for q in quads])
+    res = {"loss": loss, **{k: v for k, v in metrics.items()}}
+    params = [(n, p) for n, p in m.named_parameters()]
+    g = torch.autograd.grad(loss, lv[3:] + [p for _, p in params], allow_unused=True)
+    for i, gi in enumerate(g[:3]):
+        if gi is not None:
+            res[f"gin{i}"] = gi
+    for (n, _), gp in zip(params, g[3:]):
+        if gp is not None:
+            res[f"gp.{n}"] = gp
+    return res
+
+
+_register("quad_training_step", _quad_build, _is_inputs, _quad_train_run, True, needs="quad")

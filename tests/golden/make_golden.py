@@ -13,7 +13,7 @@ and each hot-path file is executed with importlib from where it lies:
   layers/{convblocks,pooling,scalers,bifpn}.py  - need only torch/einops/numpy: run UNMODIFIED
   layers/fpn.py, layers/hybrid_encoder.py, utils/__init__.py (+ polygon_iou, pck, f1), heads/object_detection.py,
   heads/semantic_segmentation.py, heads/instance_segmentation.py, heads/depth_estimation.py,
-  heads/keypoint_detection.py
+  heads/keypoint_detection.py, heads/quadrilateral_detection.py
       - additionally import ``torchvision.ops`` / ``torchmetrics``.  Stand-in modules are
         registered for those imports: ``ops.Conv2dNormActivation`` / ``ops.MLP`` (compositions
         of torch.nn layers, documented structure) and ``ops.complete_box_iou[_loss]`` (published
@@ -68,6 +68,7 @@ def load_reference():
     ops.complete_box_iou = oh.complete_box_iou
     ops.complete_box_iou_loss = lambda a, b, reduction="none", eps=1e-7: oh.complete_box_iou_loss(a, b, eps)
     ops.masks_to_boxes = oh.masks_to_boxes
+    ops.sigmoid_focal_loss = lambda x, t, alpha=0.25, gamma=2.0, reduction="none": oh.sigmoid_focal_loss(x, t, alpha, gamma)
     tv.ops = ops
     sys.modules["torchvision"], sys.modules["torchvision.ops"] = tv, ops
     tm = types.ModuleType("torchmetrics")
@@ -106,7 +107,7 @@ def load_reference():
     tmr.MeanAbsoluteError, tmr.MeanSquaredError = type("MeanAbsoluteError", (), {}), type("MeanSquaredError", (), {})
     sys.modules["torchmetrics.regression"] = tmr
     for name in ("object_detection", "semantic_segmentation", "instance_segmentation", "depth_estimation",
-                 "keypoint_detection"):
+                 "keypoint_detection", "quadrilateral_detection"):
         mod = _load(f"sihl.heads.{name}", f"heads/{name}.py")
         for k, v in vars(mod).items():
             if isinstance(v, type) and v.__module__ == mod.__name__:
@@ -125,7 +126,7 @@ def _flatten(prefix, obj, out):
 
 
 PINNED = {"layers": "reference-unmodified", "fpn": "reference+tv-standins",
-          "od": "reference+tv-standins", "semseg": "reference+tv-standins", "iseg": "reference+tv-standins", "depth": "reference+tv-standins", "hybrid": "reference+tv-standins", "kpt": "reference+tv-standins"}
+          "od": "reference+tv-standins", "semseg": "reference+tv-standins", "iseg": "reference+tv-standins", "depth": "reference+tv-standins", "hybrid": "reference+tv-standins", "kpt": "reference+tv-standins", "quad": "reference+tv-standins"}
 
 
 def main(argv):
