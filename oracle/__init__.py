@@ -29,6 +29,10 @@ from oracle.layers import (  # noqa: F401
 )
 from oracle.heads import (  # noqa: F401
     ObjectDetection,
+    QuadrilateralDetection,
+    KeypointDetection,
+    InstanceSegmentation,
+    DepthEstimation,
     SemanticSegmentation,
     SPPM,
     UAFM,

@@ -42,7 +42,7 @@ def _compare(name, res, gold, rtol, atol):
             torch.testing.assert_close(r.float(), g.float(), rtol=rtol, atol=a, msg=lambda s: f"{name}:{k}: {s}")
 
 
-@pytest.mark.parametrize("name", _cases({"layers", "fpn", "od", "semseg", "iseg", "depth", "hybrid", "kpt"}))
+@pytest.mark.parametrize("name", _cases({"layers", "fpn", "od", "semseg", "iseg", "depth", "hybrid", "kpt", "quad"}))
 def test_hip_fp32_matches_reference(name):
     data = load_npz(name)
     m, res = replay(CASES[name], _ns(), data, device="cuda", dtype=torch.float32)

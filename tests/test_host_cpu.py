@@ -69,6 +69,9 @@ def test_no_cpu_fallback():
     lambda ns: ns.FPN([3, 64, 256, 512, 1024, 2048], 256, 3, 5),
     lambda ns: ns.FPN([3, 64, 256, 512, 1024, 2048], 256, 3, 7),
     lambda ns: ns.ObjectDetection([3, 64, 256] + [256] * 5, 80, 3, 7),
+    lambda ns: ns.QuadrilateralDetection([3, 64, 256] + [256] * 5, 5, 3, 7),
+    lambda ns: ns.KeypointDetection([3, 64, 256] + [256] * 5, 17, 3, 5, 7),
+    lambda ns: ns.InstanceSegmentation([3, 64, 256] + [256] * 5, 80, 3, 3, 7),
     lambda ns: ns.ResNetBackbone("resnet50"),
     lambda ns: ns.ResNetBackbone("resnet18", top_level=7),
 ])
