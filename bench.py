@@ -112,14 +112,21 @@ def main():
     ap.add_argument("--backbone", default="native", choices=["torch", "native"],
                     help="native (default) = ResNet50 residual stages on the sihl HIP kernels; torch = trunk on "
                          "PyTorch-ROCm/MIOpen")
-    ap.add_argument("--no-graph", action="store_true",
-                    help="run the timed steps eagerly (default at N=1: the whole step replays one HIP graph)")
+    ap.add_argument("--graph", action="store_true",
+                    help="N=1 only: capture the whole step into one HIP graph and replay it (single-stream: a "
+                         "multi-branch graph replays slower than eager two-stream launches on this runtime)")
+    ap.add_argument("--no-graph", action="store_true", help="(default since the wgrad side stream; kept for old commands)")
+    ap.add_argument("--wgrad-stream", default="all", choices=["off", "small", "all"],
+                    help="weight-gradient kernels on a second HIP stream beside the dgrad chain (Trainer.wgrad_stream)")
     ap.add_argument("--profile-steps", type=int, default=3,
                     help="eager steps after the timed region over which the per-kernel HIP-event timings of the "
                          "roofline object are taken")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (with --backend gloo on a one-GPU box)")
+    ap.add_argument("--rehearse-dp", action="store_true",
+                    help="N=1 only: run the multi-GPU code path (process group of one rank, gradient buckets, hooks, "
+                         "all-reduce calls on the collective's stream) on a single GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -132,8 +139,11 @@ def main():
     dev_index = 0 if args.same_device else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    if world > 1 or args.rehearse_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -149,9 +159,10 @@ def main():
                                    ObjectDetection=sihl_amd.heads.ObjectDetection, SihlModel=sihl_amd.SihlModel)
     model = build_model(hip_ns, device, native_backbone=args.backbone == "native")
     amp = torch.bfloat16 if args.dtype == "bf16" else None
-    use_graph = world == 1 and not args.no_graph
+    use_graph = world == 1 and args.graph and not args.no_graph and not args.rehearse_dp
     trainer = Trainer(model, lr=1e-4, weight_decay=1e-4, backbone_lr_factor=0.1, grad_clip_norm=0.1,
-                      autocast_dtype=amp, graph=use_graph)
+                      autocast_dtype=amp, graph=use_graph, wgrad_stream=args.wgrad_stream,
+                      force_buckets=args.rehearse_dp)
     images, targets = synthetic_batch(args.batch, args.size, device, seed=rank)
     # graph mode needs its eager warm-up steps + the capture before the timed region
     n_warm = max(args.warmup, Trainer.GRAPH_WARMUP + 1) if use_graph else args.warmup
@@ -181,6 +192,7 @@ def main():
     # the same workload right after the timed region.  Timing events are queue barriers (~3 us of GPU time each, 700
     # per step = 2 ms, 5 % of a step) and a graph replay cannot carry them, so the timed steps themselves run without.
     profiled_steps = max(1, args.profile_steps)
+    trainer.wgrad_stream = "off"  # per-kernel durations are taken with every launch alone on the device
     lib.sihl_profile_enable(1)
     for _ in range(profiled_steps):
         trainer._eager_step(images, targets)
@@ -254,7 +266,9 @@ def main():
                        "image": f"3x{args.size}x{args.size}", "parallelism": f"dp{world}",
                        "backbone": "resnet50 trunk on " + ("sihl HIP kernels (stem on PyTorch-ROCm)"
                                                             if args.backbone == "native" else "PyTorch-ROCm (MIOpen/CK)"),
-                       "execution": "one HIP graph replay per step" if use_graph else "eager launches",
+                       "wgrad_stream": "off" if use_graph else args.wgrad_stream,
+                       "execution": "one HIP graph replay per step" if use_graph else
+                       "eager launches, weight gradients on a second HIP stream" if args.wgrad_stream != "off" else "eager launches",
                        "final_loss": final_loss},
             "roofline": roofline,
         }

@@ -85,6 +85,73 @@ def workspace(nbytes: int, device) -> Tensor:
     return buf
 
 
+# ---- weight gradients on a side stream
+# In backward the critical chain is dgrad -> norm backward -> dgrad ...; a layer's weight gradient hangs off that chain
+# (nothing reads it before the optimizer / the gradient all-reduce).  At the small pyramid levels and in the heads both
+# kernels leave most of the 256 CUs idle, so the wgrad launches go to a second HIP stream: fork after the tensor they
+# read is produced, one join before the gradients are consumed.  The operands (x, dz) are main-stream allocations the
+# side stream reads, so they are held alive until the join (the caching allocator would otherwise hand their blocks
+# to later main-stream kernels while the wgrad is still queued).
+class _Side:
+    __slots__ = ("stream", "holds", "mode", "dirty")
+
+    def __init__(self, stream, mode):
+        self.stream, self.holds, self.mode, self.dirty = stream, [], mode, False
+
+
+_SIDE: Optional[_Side] = None
+_SIDE_STREAMS = {}
+WGRAD_SIDE_MAX_PIXELS = {"off": 0, "small": 32 * 32 * 32, "all": 1 << 62}
+
+
+class wgrad_side_stream:
+    """Context manager around ``loss.backward()``.  mode: "off", "small" (layers with at most 32 768 output pixels: the
+    launches that cannot fill the chip) or "all".
+
+    priority: HIP stream priority of the side stream.  Normal-priority streams share a small pool of hardware queues
+    (GPU_MAX_HW_QUEUES, default 4) that the runtime hands out in creation order; once a process group exists (RCCL
+    and torch's collective stream take queues first) the side stream can land on the MAIN stream's hardware queue,
+    where the fork/join edges cost more than they gain (measured on one MI355X, multi-GPU code path on one rank:
+    40.1 ms/step against 37.9 single-stream; with 2, 3 or 8 hardware queues 36.0-36.6).  A high-priority stream
+    (-1) gets a queue of its own whatever else exists (36.2 ms); without a process group the normal-priority stream
+    is the better one (35.1-35.4 against 36.0), so the Trainer picks by ``dist.is_initialized()``."""
+
+    def __init__(self, mode: str = "all", device=None, priority: int = 0):
+        self.mode, self.device, self.priority = mode, device, priority
+
+    def __enter__(self):
+        global _SIDE
+        self._outer = _SIDE
+        if self.mode != "off" and torch.cuda.is_available():
+            dev = torch.cuda.current_device() if self.device is None else torch.device(self.device).index
+            key = (dev, self.priority)
+            if key not in _SIDE_STREAMS:
+                _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev, priority=self.priority)
+            _SIDE = _Side(_SIDE_STREAMS[key], self.mode)
+        else:
+            _SIDE = None
+        return self
+
+    def __exit__(self, *exc):
+        global _SIDE
+        join_side_stream()
+        _SIDE = self._outer
+        return False
+
+
+def side_stream_in_use():
+    """The wgrad side stream if weight gradients have been queued on it since the last join, else None."""
+    return _SIDE.stream if _SIDE is not None and _SIDE.dirty else None
+
+
+def join_side_stream() -> None:
+    """The current stream waits for every weight gradient queued on the side stream so far."""
+    if _SIDE is not None and _SIDE.dirty:
+        torch.cuda.current_stream().wait_stream(_SIDE.stream)
+        _SIDE.holds.clear()
+        _SIDE.dirty = False
+
+
 def nhwc(x: Tensor) -> Tensor:
     """(N,C,H,W)-logical tensor -> contiguous (N,H,W,C) view (copies only if not channels_last)."""
     return x.permute(0, 2, 3, 1).contiguous()
@@ -230,10 +297,20 @@ def conv2d_wgrad_raw(x: Tensor, dout: Tensor, KH: int, KW: int, stride: int, pad
     Cout = dout.shape[-1]
     lib = _C.lib()
     nbytes = lib.sihl_conv2d_wgrad_ws_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x))
-    ws = workspace(nbytes, x.device)
-    dw = torch.empty((Cout, KH, KW, Cin), dtype=torch.float32, device=x.device)
-    rc = lib.sihl_conv2d_wgrad(_p(x), _p(dout), _p(dw), N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x), 0,
-                               _p(ws), ws.numel(), _stream())
+    dw = torch.empty((Cout, KH, KW, Cin), dtype=torch.float32, device=x.device)  # main-stream allocation either way
+    side = _SIDE
+    if side is not None and dout.numel() // Cout <= WGRAD_SIDE_MAX_PIXELS[side.mode]:
+        side.stream.wait_stream(torch.cuda.current_stream())  # x and dout are complete on the main stream
+        with torch.cuda.stream(side.stream):
+            ws = workspace(nbytes, x.device)  # the side stream's own scratch buffer (keyed by stream)
+            rc = lib.sihl_conv2d_wgrad(_p(x), _p(dout), _p(dw), N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x),
+                                       0, _p(ws), ws.numel(), _stream())
+        side.holds.append((x, dout))
+        side.dirty = True
+    else:
+        ws = workspace(nbytes, x.device)
+        rc = lib.sihl_conv2d_wgrad(_p(x), _p(dout), _p(dw), N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x), 0,
+                                   _p(ws), ws.numel(), _stream())
     check(rc, "sihl_conv2d_wgrad")
     return dw
 

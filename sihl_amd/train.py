@@ -53,13 +53,16 @@ class GradientAverager:
     (RCCL runs it on its own stream over xGMI while backward continues).  ``finish()`` waits and scatters the
     averages back, again one multi-tensor copy per bucket."""
 
-    def __init__(self, params: Sequence[Tensor], group=None, bucket_mb: float = 32.0):
+    def __init__(self, params: Sequence[Tensor], group=None, bucket_mb: float = 32.0, force: bool = False):
+        """force: build the buckets and issue the all-reduces even in a one-rank group (single-GPU rehearsal of the
+        multi-GPU step: same hooks, same streams, same collective calls)."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.params = [p for p in params if p.requires_grad]
         self.buckets: List[Dict[str, Any]] = []
         self.where: Dict[int, Any] = {}
-        if self.world == 1:
+        self.active = self.world > 1 or (force and dist.is_initialized())
+        if not self.active:
             return
         cap = int(bucket_mb * (1 << 20) // 4)
         cur: List[Tensor] = []
@@ -93,6 +96,22 @@ class GradientAverager:
 
     def _launch(self, b) -> None:
         grads = [p.grad for p in b["params"]]
+        side = None
+        if any(g is not None and g.is_cuda for g in grads):
+            from sihl_amd import ops
+
+            side = ops.side_stream_in_use()
+        if side is None:
+            self._pack_and_reduce(b, grads)
+            return
+        # Weight gradients of this bucket may still be queued on the wgrad side stream.  Rather than stalling the
+        # main stream (the dgrad chain) until they are final, the bucket is packed ON the side stream, behind them,
+        # and the collective is ordered after that stream: the main stream never waits inside backward.
+        side.wait_stream(torch.cuda.current_stream())  # gradients produced on the main stream (norm / bias grads)
+        with torch.cuda.stream(side):
+            self._pack_and_reduce(b, grads)
+
+    def _pack_and_reduce(self, b, grads) -> None:
         if any(g is None for g in grads):  # a parameter without gradient this step contributes zeros
             b["flat"].zero_()
         pairs = [(v, g) for v, g in zip(b["views"], grads) if g is not None]
@@ -107,7 +126,7 @@ class GradientAverager:
             self._launch(b)
 
     def finish(self) -> None:
-        if self.world == 1:
+        if not self.active:
             return
         for b in self.buckets:
             if b["work"] is None:  # some parameter of this bucket got no gradient this step
@@ -169,8 +188,14 @@ class Trainer:
     def __init__(self, model: nn.Module, optimizer: Optional[torch.optim.Optimizer] = None, group=None,
                  grad_clip_norm: Optional[float] = 0.1, autocast_dtype: Optional[torch.dtype] = None,
                  bucket_mb: float = 32.0, graph: bool = False, scheduler=None,
-                 scheduler_kwargs: Optional[Dict[str, Any]] = None, **opt_kw):
+                 scheduler_kwargs: Optional[Dict[str, Any]] = None, wgrad_stream: str = "all",
+                 force_buckets: bool = False, **opt_kw):
         self.model = model
+        # eager steps launch weight gradients on a second HIP stream beside the dgrad chain (ops.wgrad_side_stream):
+        # "off" | "small" | "all".  Measured on one MI355X, flagship step: eager off 854, small 866, all 912 img/s; a
+        # captured graph with those fork/join edges replays SLOWER (830 vs 854 single-stream), so captures stay
+        # single-stream.
+        self.wgrad_stream = wgrad_stream
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         on_gpu = all(p.is_cuda for p in model.parameters())
         self.use_graph = bool(graph) and world == 1 and on_gpu
@@ -180,7 +205,8 @@ class Trainer:
         self.grad_clip_norm = grad_clip_norm
         self.autocast_dtype = autocast_dtype
         broadcast_parameters(model, group=group)
-        self.averager = GradientAverager(list(model.parameters()), group=group, bucket_mb=bucket_mb)
+        self.averager = GradientAverager(list(model.parameters()), group=group, bucket_mb=bucket_mb,
+                                         force=force_buckets)
         self._graphs: Dict[Any, Any] = {}
         self._seen: Dict[Any, int] = {}
         self.scheduler = self._make_scheduler(scheduler, dict(scheduler_kwargs or {}))
@@ -256,10 +282,21 @@ class Trainer:
             metrics.update({f"head{i}/train/{k}": v for k, v in m.items()})
         return torch.stack(losses).sum(), metrics
 
+    def _backward(self, loss: Tensor) -> None:
+        if self.wgrad_stream == "off" or not loss.is_cuda or torch.cuda.is_current_stream_capturing():
+            loss.backward()
+            return
+        from sihl_amd import ops
+
+        # with a process group the side stream is a high-priority one (a hardware queue of its own, see ops)
+        prio = -1 if dist.is_initialized() else 0
+        with ops.wgrad_side_stream(self.wgrad_stream, loss.device, prio):  # joins the side stream on exit
+            loss.backward()
+
     def _eager_step(self, images: Tensor, targets: List[Any]):
         self.optimizer.zero_grad(set_to_none=True)
         loss, metrics = self.forward_loss(images, targets)
-        loss.backward()
+        self._backward(loss)
         self.averager.finish()
         if self.grad_clip_norm is not None:
             torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.grad is not None],
@@ -278,7 +315,7 @@ class Trainer:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             loss, metrics = self.forward_loss(static_images, static_targets)
-            loss.backward()
+            self._backward(loss)
             if self.grad_clip_norm is not None:
                 torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.grad is not None],
                                                self.grad_clip_norm)
