@@ -99,6 +99,42 @@ def cpu_baseline(sample_batch, size, iters=4):
                       f"workload, mean of {iters} steps after 1 warm-up ({dt:.2f} s/step)"}
 
 
+def north_star_forward(model, device, dtype, batch, size, iters=20):
+    """The north-star sub-metric, measured live: BiFPN + ObjectDetection.forward (eval, inference kernels: BatchNorm
+    folded into the conv epilogues) on a seeded ResNet50-shaped level list, HIP events around `iters` forwards.
+    Algorithmic work per image: 45.64 + 3.69 GFLOP, 85.8 + 8.5 MB (bf16) at 512^2."""
+    if size != 512:
+        return None
+    chans = [3, 64, 256, 512, 1024, 2048]
+    g = torch.Generator(device=device).manual_seed(1)
+    levels = [torch.zeros(batch, 3, size, size, device=device)] + [
+        torch.randn(batch, c, size // 2 ** l, size // 2 ** l, device=device, generator=g).to(dtype)
+        .contiguous(memory_format=torch.channels_last) for l, c in enumerate(chans) if l > 0]
+    was_training = model.training
+    model.eval()
+    try:
+        with torch.no_grad():
+            for _ in range(3):
+                model.heads[0](model.neck(levels))
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                model.heads[0](model.neck(levels))
+            e1.record()
+            torch.cuda.synchronize()
+    finally:
+        model.train(was_training)
+    ms = e0.elapsed_time(e1) / iters
+    es = 2 if dtype == torch.bfloat16 else 4
+    gflop, mbytes = batch * (45.64 + 3.69), batch * (42.9 + 4.26) * es
+    peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else 157.3
+    return {"what": f"BiFPN(3-7) + ObjectDetection.forward, eval, bs {batch}, {size}x{size}, seeded level list",
+            "ms": ms, "images_per_s": batch / ms * 1e3, "achieved_tflops": gflop / ms, "peak_tflops": peak,
+            "frac_of_mfma_roofline": gflop / ms / peak, "algorithmic_hbm_gbps": mbytes / ms,
+            "frac_of_hbm_roofline": mbytes / ms / 8000.0, "bound": "mfma (AI 520 flop/B against a ridge of ~310)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,6 +154,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="(default since the wgrad side stream; kept for old commands)")
     ap.add_argument("--wgrad-stream", default="all", choices=["off", "small", "all"],
                     help="weight-gradient kernels on a second HIP stream beside the dgrad chain (Trainer.wgrad_stream)")
+    ap.add_argument("--wgrad-target", type=int, default=0,
+                    help="tuning: workgroups the LDS-DMA wgrad kernel's K-split aims for (0 = library default)")
     ap.add_argument("--profile-steps", type=int, default=3,
                     help="eager steps after the timed region over which the per-kernel HIP-event timings of the "
                          "roofline object are taken")
@@ -175,10 +213,12 @@ def main():
     trace = (lambda m: print(f"[bench] {m}", file=sys.stderr, flush=True)) if os.environ.get("SIHL_BENCH_TRACE") \
         else (lambda m: None)
 
+    lib = _C.lib()
+    if args.wgrad_target:
+        lib.sihl_conv2d_wgrad_target(args.wgrad_target)
     for i in range(n_warm):
         trainer.step(images, targets)
         trace(f"warm-up step {i} issued")
-    lib = _C.lib()
     sync()
     trace("warm-up done")
     t0 = time.perf_counter()
@@ -199,6 +239,11 @@ def main():
     sync()
     trace("profiled eager steps done")
     lib.sihl_profile_enable(0)
+
+    fwd = None
+    if world == 1 and rank == 0 and not args.rehearse_dp:
+        fwd = north_star_forward(model, device, amp or torch.float32, args.batch, args.size)
+        trace("north-star forward probe done")
 
     t = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
@@ -272,6 +317,8 @@ def main():
                        "final_loss": final_loss},
             "roofline": roofline,
         }
+        if fwd is not None:
+            out["north_star_forward"] = fwd
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.size)
         print(json.dumps(out), flush=True)

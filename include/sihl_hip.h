@@ -87,6 +87,10 @@ int sihl_conv2d_rules_off(int mask);   /* tuning hook: disable individual dispat
 /* Test hook: bf16 layers with >= 128 channels use an LDS-DMA 256x256-panel kernel; on != 0 forces the
  * register-staged 128x128 kernel (the fp32 / small-channel path) so both stay parity-tested. */
 int sihl_conv2d_wgrad_force_register_staging(int on);
+/* K-split target (workgroups) of the wgrad kernels: workgroups % 10000 for the LDS-DMA kernel (0 = 256, one per CU),
+ * workgroups / 10000 for the register-staged / all-taps kernels (0 = default).  Process-wide; the workspace query
+ * follows it.  The two-stream training step sets 128 / 128 while weight gradients run beside the dgrad chain. */
+int sihl_conv2d_wgrad_target(int workgroups);
 long sihl_conv2d_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                 int dil, int dtype);
 int sihl_conv2d_wgrad(const void* in, const void* dout, float* dw, int N, int H, int W, int Cin, int Cout, int KH,

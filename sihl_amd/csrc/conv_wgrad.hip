@@ -515,6 +515,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 }
 
 bool g_wgrad_force_reg = false;
+int g_wgrad_target = 0;  // tuning hook: workgroups the LDS-DMA kernel's K-split aims for (0 = default)
+int g_wgrad_target_reg = 0;  // same for the register-staged and all-taps kernels (0 = default)
 
 bool use_dma(int Cin, int Cout, long in_bytes, long dy_bytes, int dtype) {
   // exactly 128x128 channels would leave three quarters of the 256x256 panel empty (228 us against 130 us for the
@@ -557,7 +559,7 @@ WgradPlan plan_wgrad(long M, int N, int H, int W, int Cin, int Cout, int KH, int
     pl.mode = 2; pl.kp = SKP;
     pl.tiles_co = (Cout + SCO - 1) / SCO; pl.tiles_ci = (Cin + SCI - 1) / SCI;
     // one workgroup per CU (120 KiB of LDS): 256 workgroups, at least 8 stages each
-    long s = 256 / (pl.tiles_co * pl.tiles_ci), by_work = M / (8L * SKP);
+    long s = (g_wgrad_target_reg > 0 ? g_wgrad_target_reg : 256) / (pl.tiles_co * pl.tiles_ci), by_work = M / (8L * SKP);
     if (s > by_work) s = by_work;
     if (s < 1) s = 1;
     pl.splits = (int)s;
@@ -568,7 +570,7 @@ WgradPlan plan_wgrad(long M, int N, int H, int W, int Cin, int Cout, int KH, int
   pl.mode = dma ? 1 : 0;
   pl.kp = dtype == SIHL_BF16 ? 64 : 32;
   pl.tiles_co = (Cout + tb - 1) / tb; pl.tiles_ci = (Cin + tb - 1) / tb;
-  pl.splits = choose_splits(M, KH * KW * pl.tiles_co * pl.tiles_ci, pl.kp, dma ? 256 : 512, n_weights);
+  pl.splits = choose_splits(M, KH * KW * pl.tiles_co * pl.tiles_ci, pl.kp, dma ? (g_wgrad_target > 0 ? g_wgrad_target : 256) : (g_wgrad_target_reg > 0 ? 2 * g_wgrad_target_reg : 512), n_weights);
   return pl;
 }
 
@@ -633,6 +635,9 @@ extern "C" {
 
 // Test hook: 1 = always use the register-staged 128x128 kernel (the fp32 / small-channel path).
 int sihl_conv2d_wgrad_force_register_staging(int on) { g_wgrad_force_reg = on != 0; return 0; }
+// Tuning hook: workgroups the LDS-DMA wgrad kernel's K-split aims for (0 = default, one per CU).  Fewer, longer
+// workgroups write fewer fp32 partial slabs and leave CUs to the kernels of the other stream.
+int sihl_conv2d_wgrad_target(int workgroups) { g_wgrad_target = workgroups % 10000; g_wgrad_target_reg = workgroups / 10000; return 0; }
 
 // Workspace bytes sihl_conv2d_wgrad needs for this problem.
 long sihl_conv2d_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,

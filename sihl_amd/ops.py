@@ -102,6 +102,7 @@ class _Side:
 _SIDE: Optional[_Side] = None
 _SIDE_STREAMS = {}
 WGRAD_SIDE_MAX_PIXELS = {"off": 0, "small": 32 * 32 * 32, "all": 1 << 62}
+SIDE_WGRAD_TARGET = 128 + 10000 * 128  # sihl_conv2d_wgrad_target: LDS-DMA kernel + 10000 x register-staged kernels
 
 
 class wgrad_side_stream:
@@ -128,6 +129,10 @@ class wgrad_side_stream:
             if key not in _SIDE_STREAMS:
                 _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev, priority=self.priority)
             _SIDE = _Side(_SIDE_STREAMS[key], self.mode)
+            # beside the dgrad chain a weight gradient should not claim the whole chip: K-splits aimed at 128
+            # workgroups instead of one per CU write half the fp32 partial slabs and leave CUs to the main stream
+            # (flagship step, same box: 35.4-35.8 -> 34.4-34.7 ms; 64-96 workgroups about the same, 32: 40.2 ms)
+            _C.lib().sihl_conv2d_wgrad_target(SIDE_WGRAD_TARGET)
         else:
             _SIDE = None
         return self
@@ -135,6 +140,8 @@ class wgrad_side_stream:
     def __exit__(self, *exc):
         global _SIDE
         join_side_stream()
+        if _SIDE is not None:
+            _C.lib().sihl_conv2d_wgrad_target(0)
         _SIDE = self._outer
         return False
 

@@ -114,8 +114,9 @@ def test_object_detection_validation_reports_coco_map():
 @pytest.mark.parametrize("mode", ["small", "all"])
 def test_wgrad_side_stream_gives_identical_gradients(mode):
     """Weight gradients launched on the second HIP stream (ops.wgrad_side_stream) are the same kernels on the same
-    operands: every gradient bit-identical to the single-stream backward, repeatedly (a missing fork / join edge or
-    an operand freed too early would show as a mismatch under the allocator's block reuse)."""
+    operands: every gradient reproducible run to run and equal to the single-stream backward up to the fp32 summation
+    order of the K-splits, repeatedly (a missing fork / join edge or an operand freed too early would show as a
+    mismatch under the allocator's block reuse)."""
     from sihl_amd import ops
     from sihl_amd.train import Trainer
     model = _model()
@@ -133,15 +134,17 @@ def test_wgrad_side_stream_gives_identical_gradients(mode):
 
     ref, ref2 = grads("off"), grads("off")
     exact = all(torch.equal(ref[n], ref2[n]) for n in ref)  # (atomics in the loss backward may reorder last bits)
+    first = grads(mode)
+    assert set(first) == set(ref)
     for _ in range(3):
         got = grads(mode)
-        assert set(got) == set(ref)
         for n in ref:
+            # beside the dgrad chain the K-splits are fewer and longer (other fp32 summation order): the same run twice
+            # is bit-identical, against the single-stream gradients it agrees to fp32 rounding
             if exact:
-                assert torch.equal(got[n], ref[n]), n
-            else:
-                scale = float(ref[n].abs().max()) + 1e-12
-                assert float((got[n] - ref[n]).abs().max()) <= 1e-4 * scale, n
+                assert torch.equal(got[n], first[n]), n
+            scale = float(ref[n].abs().max()) + 1e-12
+            assert float((got[n] - ref[n]).abs().max()) <= 1e-4 * scale, n
     assert ops._SIDE is None  # the context manager restored the single-stream state
 
 
