@@ -7,6 +7,7 @@ training_step: same laterals + MLPs (matrix-core kernels with hand-written backw
 matching and the four losses are fp32 device ops, as in the reference's autocast-disabled islands.
 """
 from functools import partial
+from types import SimpleNamespace
 from typing import Dict, List, Tuple
 
 import torch
@@ -89,6 +90,46 @@ class ObjectDetection(nn.Module):
         return out
 
     # ------------------------------------------------------------------ training
+    def _targets(self, level_hw, W: int, H: int, classes: List[Tensor], boxes: List[Tensor], device):
+        """Everything of the loss that depends on the targets and the anchor grid only - not on the network's output:
+        padded ground truths, the matching (reference :139-148, :252-284), the location / IoU targets and the
+        fixed-size candidate rows with their weights (see training_step).  The Trainer computes it on the side stream
+        while the backbone runs (``prematch``)."""
+        t = SimpleNamespace()
+        t.full = self._full_size(W, H, device)
+        t.offsets, t.scales = ops.od_anchors(level_hw, device)
+        anchors = (t.offsets + t.scales) * t.full
+        gt, gt_cls, col_ok = self._pad_targets(boxes, classes, device)
+        assignment, t.rel_iou, top_i = self._match_padded(anchors, gt, col_ok, self.topk)
+        t.num_gt = gt.shape[1]
+        t.loc_target = (t.rel_iou == 1.0).to(torch.float32)
+        t.loc_norm = t.loc_target.sum()
+        if t.num_gt == 0:
+            return t
+        B, P = t.rel_iou.shape
+        G, K = gt.shape[1], top_i.shape[1]
+        cand = top_i.permute(0, 2, 1).reshape(B, G * K)  # anchor index of candidate (image, gt, rank)
+        cand_gt = torch.arange(G, device=device).repeat_interleave(K)[None, :].expand(B, -1)
+        mine = (torch.gather(assignment, 1, cand) == cand_gt) & col_ok.repeat_interleave(K, dim=1)
+        t.wts = (torch.gather(t.rel_iou, 1, cand) * mine).reshape(-1)  # 0 for rows the reference does not select
+        t.rows = (cand + torch.arange(B, device=device)[:, None] * P).reshape(-1)
+        t.anchor_of = cand.reshape(-1)
+        t.tgt_box = torch.gather(gt, 1, cand_gt[..., None].expand(-1, -1, 4)).reshape(-1, 4) / t.full
+        t.tgt_cls = torch.gather(gt_cls, 1, cand_gt).reshape(-1)
+        t.wsum = t.wts.sum()
+        t.iou_norm = t.rel_iou.sum()
+        t.cand_offsets, t.cand_scales = t.offsets[t.anchor_of], t.scales[t.anchor_of]
+        t.none_matched = t.rel_iou.max() == 0  # degenerate ground truths only; stays on the device
+        return t
+
+    def prematch(self, image_hw: Tuple[int, int], classes: List[Tensor], boxes: List[Tensor], device) -> None:
+        """Compute the target-only part of the next training_step now (the Trainer calls this on its side stream before
+        the backbone runs; the level sizes follow the backbone's contract, level l = image / 2^l, and are checked
+        against the real feature maps when the result is used)."""
+        H, W = int(image_hw[0]), int(image_hw[1])
+        level_hw = [(H >> l, W >> l) for l in self.levels]
+        self._prematched = (level_hw, (H, W), id(classes), id(boxes), self._targets(level_hw, W, H, classes, boxes, device))
+
     def training_step(self, inputs: List[Tensor], classes: List[Tensor], boxes: List[Tensor],
                       is_validating: bool = False) -> Tuple[Tensor, Dict[str, float]]:
         """Loss of the reference (:124-217), arranged so that the host never waits for the device: no boolean-mask
@@ -99,46 +140,34 @@ class ObjectDetection(nn.Module):
         assert len(inputs) > self.top_level, "too few input levels"
         device = inputs[self.bottom_level].device
         B, _, H, W = inputs[0].shape
-        full = self._full_size(W, H, device)
-        offsets, scales = self.get_offsets_and_scales(inputs)
-        anchors = (offsets + scales) * full
-        gt, gt_cls, col_ok = self._pad_targets(boxes, classes, device)
-        assignment, rel_iou, top_i = self._match_padded(anchors, gt, col_ok, self.topk)
+        level_hw = self._level_hw(inputs)
+        pm, self._prematched = getattr(self, "_prematched", None), None
+        if pm is not None and pm[0] == level_hw and pm[1] == (H, W) and pm[2] == id(classes) and pm[3] == id(boxes):
+            t = pm[4]
+        else:
+            t = self._targets(level_hw, W, H, classes, boxes, device)
 
         flat = self._flat_feats(inputs)
         P, C = flat.shape[1], flat.shape[2]
         loc_logits = self.loc_head(flat.view(B * P, C)).reshape(B, P)
-        loc_target = (rel_iou == 1.0).to(torch.float32)
-        loc_loss = F.binary_cross_entropy_with_logits(loc_logits.float(), loc_target, reduction="none")
-        loc_loss = loc_loss.sum() / loc_target.sum()
+        loc_loss = F.binary_cross_entropy_with_logits(loc_logits.float(), t.loc_target, reduction="none")
+        loc_loss = loc_loss.sum() / t.loc_norm
         z = torch.zeros_like(loc_loss)
-        if gt.shape[1] == 0:  # no ground truth in the whole batch (host-side shapes): reference early-out :165-172
+        if t.num_gt == 0:  # no ground truth in the whole batch (host-side shapes): reference early-out :165-172
             return loc_loss, {"location_loss": loc_loss, "box_loss": z, "class_loss": z, "iou_loss": z}
 
         iou_preds = self.iou_head(flat.view(B * P, C)).reshape(B, P)
-        iou_loss = F.mse_loss(iou_preds.float(), rel_iou, reduction="none").sum() / rel_iou.sum()
+        iou_loss = F.mse_loss(iou_preds.float(), t.rel_iou, reduction="none").sum() / t.iou_norm
 
-        G, K = gt.shape[1], top_i.shape[1]
-        cand = top_i.permute(0, 2, 1).reshape(B, G * K)  # anchor index of candidate (image, gt, rank)
-        cand_gt = torch.arange(G, device=device).repeat_interleave(K)[None, :].expand(B, -1)
-        mine = (torch.gather(assignment, 1, cand) == cand_gt) & col_ok.repeat_interleave(K, dim=1)
-        wts = (torch.gather(rel_iou, 1, cand) * mine).reshape(-1)  # 0 for rows the reference does not select
-        rows = (cand + torch.arange(B, device=device)[:, None] * P).reshape(-1)
-        sel = torch.index_select(flat.view(B * P, C), 0, rows)
-        anchor_of = cand.reshape(-1)
-        tgt_box = torch.gather(gt, 1, cand_gt[..., None].expand(-1, -1, 4)).reshape(-1, 4) / full
-        tgt_cls = torch.gather(gt_cls, 1, cand_gt).reshape(-1)
-        wsum = wts.sum()
+        sel = torch.index_select(flat.view(B * P, C), 0, t.rows)
+        box_preds = t.cand_offsets + t.cand_scales * self.box_head(sel).float().exp()
+        box_loss = (t.wts * complete_box_iou_loss(box_preds, t.tgt_box)).sum() / t.wsum
 
-        box_preds = offsets[anchor_of] + scales[anchor_of] * self.box_head(sel).float().exp()
-        box_loss = (wts * complete_box_iou_loss(box_preds, tgt_box)).sum() / wsum
+        cls_loss = F.cross_entropy(self.cls_head(sel).float(), t.tgt_cls, reduction="none")
+        cls_loss = (t.wts * cls_loss).sum() / t.wsum
 
-        cls_loss = F.cross_entropy(self.cls_head(sel).float(), tgt_cls, reduction="none")
-        cls_loss = (wts * cls_loss).sum() / wsum
-
-        none_matched = rel_iou.max() == 0  # degenerate ground truths only; stays on the device
-        pick = lambda t: torch.where(none_matched, z, t)  # noqa: E731
-        loss = torch.where(none_matched, loc_loss, loc_loss + 10 * box_loss + cls_loss + iou_loss)
+        pick = lambda v: torch.where(t.none_matched, z, v)  # noqa: E731
+        loss = torch.where(t.none_matched, loc_loss, loc_loss + 10 * box_loss + cls_loss + iou_loss)
         return loss, {"location_loss": loc_loss, "box_loss": pick(box_loss), "class_loss": pick(cls_loss),
                       "iou_loss": pick(iou_loss)}
 

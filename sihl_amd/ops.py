@@ -105,6 +105,17 @@ WGRAD_SIDE_MAX_PIXELS = {"off": 0, "small": 32 * 32 * 32, "all": 1 << 62}
 SIDE_WGRAD_TARGET = 128 + 10000 * 128  # sihl_conv2d_wgrad_target: LDS-DMA kernel + 10000 x register-staged kernels
 
 
+def side_stream(device, priority: int = 0):
+    """The per-device side stream (one per priority), created on first use."""
+    dev = torch.device(device).index if not isinstance(device, int) else device
+    if dev is None:
+        dev = torch.cuda.current_device()
+    key = (dev, priority)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev, priority=priority)
+    return _SIDE_STREAMS[key]
+
+
 class wgrad_side_stream:
     """Context manager around ``loss.backward()``.  mode: "off", "small" (layers with at most 32 768 output pixels: the
     launches that cannot fill the chip) or "all".
@@ -125,10 +136,7 @@ class wgrad_side_stream:
         self._outer = _SIDE
         if self.mode != "off" and torch.cuda.is_available():
             dev = torch.cuda.current_device() if self.device is None else torch.device(self.device).index
-            key = (dev, self.priority)
-            if key not in _SIDE_STREAMS:
-                _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev, priority=self.priority)
-            _SIDE = _Side(_SIDE_STREAMS[key], self.mode)
+            _SIDE = _Side(side_stream(dev, self.priority), self.mode)
             # beside the dgrad chain a weight gradient should not claim the whole chip: K-splits aimed at 128
             # workgroups instead of one per CU write half the fp32 partial slabs and leave CUs to the main stream
             # (flagship step, same box: 35.4-35.8 -> 34.4-34.7 ms; 64-96 workgroups about the same, 32: 40.2 ms)
@@ -796,12 +804,12 @@ class LinearFn(torch.autograd.Function):
             dy = dyp
         dy = dy.contiguous()
         dx = dw = db = None
+        if ctx.needs_input_grad[1]:  # first: on the side stream it then runs beside the input gradient below
+            dw = conv2d_wgrad_raw(x.view(1, 1, rows, Cin), dy.view(1, 1, rows, Cp), 1, 1, 1, 0, 1).view(Cp, Cin)[:Cout]
         if ctx.needs_input_grad[0]:
             wt = ctx.wt if ctx.wt is not None else weight_for_dgrad(w.view(Cp, 1, 1, Cin), flip=False)  # [Cin][1][1][Cp]
             dx, _ = conv2d_raw(dy.view(1, 1, rows, Cp), wt)
             dx = dx.view(rows, Cin)
-        if ctx.needs_input_grad[1]:
-            dw = conv2d_wgrad_raw(x.view(1, 1, rows, Cin), dy.view(1, 1, rows, Cp), 1, 1, 1, 0, 1).view(Cp, Cin)[:Cout]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy)[:Cout]
         return dx, dw, db
