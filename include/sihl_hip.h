@@ -79,6 +79,13 @@ int sihl_conv2d_fwd_ws(const void* in, const void* wt, const float* bias, void* 
 int sihl_conv2d_dgrad_ws(const void* dout, const void* wt_t, void* din, const void* add, int N, int H, int W, int Cin,
                          int Cout, int KH, int KW, int stride, int pad, int dil, int dtype, void* ws, long ws_bytes,
                          hipStream_t stream);
+/* sihl_conv2d_dgrad_ws whose addend may be COMPACT: with add_stride s > 1, `add` is [N][ceil(H/s)][ceil(W/s)][Cin] -
+ * the input gradient of a stride-s 1x1 projection of the same input (ResNet downsample branch) - and is added at the
+ * pixels (y % s == 0, x % s == 0) that projection reads; the other pixels get the conv's own gradient only.  Replaces
+ * the zero-dilated dgrad of the projection plus autograd's add over the block input. */
+int sihl_conv2d_dgrad_add(const void* dout, const void* wt_t, void* din, const void* add, int add_stride, int N, int H,
+                          int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, int dtype, void* ws,
+                          long ws_bytes, hipStream_t stream);
 int sihl_conv2d_splitk_enable(int on); /* tuning / test hook */
 int sihl_conv2d_rules_off(int mask);   /* tuning hook: disable individual dispatch rules */
 

@@ -25,7 +25,7 @@ from sihl_amd.layers.scalers import AntialiasedDownscaler
 
 
 def _conv_bn(x: Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, act, training: bool, residual=None, hand_over=None,
-             take_over=None) -> Tensor:
+             take_over=None, dx_to=None) -> Tensor:
     """conv -> BatchNorm -> act on NHWC tensors through the fused HIP conv block (torchvision order); with
     ``residual`` the block tail relu(BN(conv(x)) + residual) is one normalise+add+ReLU pass."""
     if training:
@@ -33,7 +33,7 @@ def _conv_bn(x: Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, act, training: bool
     return ops.conv_block(x, conv.weight, None, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                           stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0], act=act,
                           order="norm_act", training=training, eps=bn.eps, momentum=bn.momentum, residual=residual,
-                          hand_over=hand_over, take_over=take_over)
+                          hand_over=hand_over, take_over=take_over, dx_to=dx_to)
 
 
 def _carrier(block, x: Tensor, training: bool):
@@ -41,6 +41,16 @@ def _carrier(block, x: Tensor, training: bool):
     first conv to produce an input gradient of x's shape (stride 1, x requires grad, conv1 trainable path)."""
     ok = (training and block.downsample is None and torch.is_grad_enabled() and x.requires_grad
           and block.conv1.stride[0] == 1 and not os.environ.get("SIHL_NO_GRAD_CARRIER"))  # env: A/B switch
+    return ops.GradCarrier() if ok else None
+
+
+def _proj_carrier(block, x: Tensor, training: bool):
+    """A GradCarrier for projection blocks in training: the 1x1 (possibly strided) downsample conv parks its input
+    gradient at its own output resolution and conv1's dgrad adds it at the pixels the projection reads - instead of a
+    zero-dilated dgrad over the block input plus autograd's add of the two branch gradients."""
+    ds = block.downsample[0]
+    ok = (training and torch.is_grad_enabled() and x.requires_grad and block.conv1.stride[0] == 1
+          and ds.kernel_size == (1, 1) and ds.padding == (0, 0) and not os.environ.get("SIHL_NO_GRAD_CARRIER"))
     return ops.GradCarrier() if ok else None
 
 
@@ -96,11 +106,18 @@ class _Bottleneck(nn.Module):
 
     def forward_nhwc(self, x):
         t = self.training
-        idt = x if self.downsample is None else _conv_bn(x, self.downsample[0], self.downsample[1], None, t)
-        c = _carrier(self, x, t)
+        if self.downsample is None:
+            c = _carrier(self, x, t)
+            y = _conv_bn(x, self.conv1, self.bn1, "relu", t, take_over=c)
+            y = _conv_bn(y, self.conv2, self.bn2, "relu", t)
+            return _conv_bn(y, self.conv3, self.bn3, None, t, residual=x, hand_over=c)
+        c = _proj_carrier(self, x, t)
         y = _conv_bn(x, self.conv1, self.bn1, "relu", t, take_over=c)
         y = _conv_bn(y, self.conv2, self.bn2, "relu", t)
-        return _conv_bn(y, self.conv3, self.bn3, None, t, residual=idt, hand_over=c)
+        # the projection runs AFTER conv1 so that autograd visits it first in backward (later nodes first): its compact
+        # input gradient is parked before conv1's dgrad picks it up
+        idt = _conv_bn(x, self.downsample[0], self.downsample[1], None, t, dx_to=c)
+        return _conv_bn(y, self.conv3, self.bn3, None, t, residual=idt)
 
 
 RESNETS = {"resnet18": (_Basic, [2, 2, 2, 2]), "resnet34": (_Basic, [3, 4, 6, 3]),

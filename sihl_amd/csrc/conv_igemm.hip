@@ -45,7 +45,19 @@ struct ConvParams {
   long partial_bytes;
   const void* add;  // optional tensor of the output's shape added in the epilogue (dense output only): the identity
                     // branch's gradient riding on a residual block's first dgrad instead of a separate add kernel
+  int add_stride;   // > 1: the addend is [N][add_H][add_W][Cout] and lands on output pixels (y, x) with y % add_stride
+  int add_H, add_W; // == 0 and x % add_stride == 0 only (input gradient of a strided 1x1 projection: zero elsewhere)
 };
+
+// element offset of output row m in the addend, or -1 where a strided addend has nothing to add
+__device__ __forceinline__ long add_offset(const ConvParams& p, int m) {
+  if (p.add_stride <= 1) return (long)m * p.Cout;
+  const int hw = p.Ho * p.Wo;
+  const int n = m / hw, r = m - n * hw;
+  const int y = r / p.Wo, x = r - y * p.Wo;
+  if ((y % p.add_stride) != 0 || (x % p.add_stride) != 0) return -1;
+  return (((long)n * p.add_H + y / p.add_stride) * p.add_W + x / p.add_stride) * p.Cout;
+}
 
 bool g_force_reg = false;  // test hook: use the register-staged loader
 int g_dbg = 0;
@@ -161,7 +173,8 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t
         const int idx = tid + (it0 + u) * NTHREADS;
         const int row = idx / CHUNKS, ch = idx - row * CHUNKS;
         const int m = m0 + row, co = n0 + ch * VEC;
-        av[u] = (m < p.M && co + VEC <= p.Cout) ? *(const uint4*)(addp + (long)m * p.Cout + co) : make_uint4(0, 0, 0, 0);
+        const long aoff = m < p.M ? add_offset(p, m) : -1;
+        av[u] = (aoff >= 0 && co + VEC <= p.Cout) ? *(const uint4*)(addp + aoff + co) : make_uint4(0, 0, 0, 0);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -191,7 +204,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t
     } else {
       for (int e = 0; e < VEC && co + e < p.Cout; ++e) {
         float v = elem<T>::ld((const T*)src + e);
-        if (ADD) v += elem<T>::ld((const T*)p.add + (long)m * p.Cout + co + e);
+        if (ADD) { const long aoff = add_offset(p, m); if (aoff >= 0) v += elem<T>::ld((const T*)p.add + aoff + co + e); }
         elem<T>::st(dst + e, v);
       }
     }
@@ -645,9 +658,40 @@ __global__ void conv_add_inplace_kernel(T* __restrict__ out, const T* __restrict
   }
 }
 
+// out[n][y*s][x*s][:] += add[n][y][x][:] (strided addend, see ConvParams::add_stride); C % V == 0
+template <typename T>
+__global__ void conv_add_strided_kernel(T* __restrict__ out, const T* __restrict__ add, long nvec, int C, int aH, int aW,
+                                        int oH, int oW, int s) {
+  constexpr int V = 16 / (int)sizeof(T);
+  const int cv = C / V;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv);
+    long pix = i / cv;
+    const int x = (int)(pix % aW); pix /= aW;
+    const int y = (int)(pix % aH);
+    const long n = pix / aH;
+    T* o = out + ((n * oH + (long)y * s) * oW + (long)x * s) * C + c * V;
+    float a[V], b[V];
+    unpack16(*(const uint4*)o, a, T());
+    unpack16(*(const uint4*)(add + i * V), b, T());
+#pragma unroll
+    for (int e = 0; e < V; ++e) a[e] += b[e];
+    *(uint4*)o = pack16(a, T());
+  }
+}
+
 template <typename T>
 void launch_add_inplace(const ConvParams& p, hipStream_t stream) {
   constexpr int V = 16 / (int)sizeof(T);
+  if (p.add_stride > 1) {
+    const long nv = (long)p.N * p.add_H * p.add_W * p.Cout / V;
+    long gs = (nv + 255) / 256;
+    if (gs > 4096) gs = 4096;
+    if (gs < 1) gs = 1;
+    hipLaunchKernelGGL(conv_add_strided_kernel<T>, dim3((unsigned)gs), dim3(256), 0, stream, (T*)p.out, (const T*)p.add, nv,
+                       p.Cout, p.add_H, p.add_W, p.Ho, p.Wo, p.add_stride);
+    return;
+  }
   const long nvec = (long)p.M * p.Cout / V;  // dense output, Cout % V == 0
   long g = (nvec + 255) / 256;
   if (g > 4096) g = 4096;
@@ -708,7 +752,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvPar
       else if (ACT == SIHL_ACT_SIGMOID) x = 1.f / (1.f + expf(-x));
       if (STATS == 2 && ok) { ssum[e] += x; ssq[e] += x * x; }
       o[e] = x * s2[e] + t2[e];
-      if (p.add && ok) o[e] += elem<T>::ld((const T*)p.add + (long)(mbase + k) * p.Cout + co + e);
+      if (p.add && ok) { const long aoff = add_offset(p, mbase + k); if (aoff >= 0) o[e] += elem<T>::ld((const T*)p.add + aoff + co + e); }
     }
     if (ok) {
       T* dst = out + (long)(mbase + k) * p.Cout + co;
@@ -931,6 +975,10 @@ int sihl_conv2d_dgrad_ws(const void* dout, const void* wt_t, void* din, const vo
                          int Cout, int KH, int KW, int stride, int pad, int dil, int dtype, void* ws, long ws_bytes,
                          hipStream_t stream);
 
+int sihl_conv2d_dgrad_add(const void* dout, const void* wt_t, void* din, const void* add, int add_stride, int N, int H,
+                          int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, int dtype, void* ws,
+                          long ws_bytes, hipStream_t stream);
+
 // Test hook: 1 = use the register-staged loader instead of LDS-DMA (both are kept parity-tested).
 int sihl_conv2d_force_register_staging(int on) { g_force_reg = on != 0; return 0; }
 
@@ -1005,7 +1053,7 @@ int sihl_conv2d_fwd_ws(const void* in, const void* wt, const float* bias, void* 
     if (stats_ws_bytes < (long)sihl_conv2d_stat_rows(M) * 2 * Cout * (long)sizeof(float)) return SIHL_EWS;
   }
   p.splits = 1; p.partial = (float*)ws; p.partial_bytes = ws ? ws_bytes : 0;
-  p.add = nullptr;
+  p.add = nullptr; p.add_stride = 1; p.add_H = p.add_W = 0;
   if (dtype == SIHL_F32) return dispatch<float>(p, stream);
   if (dtype == SIHL_BF16) return dispatch<bf16_t>(p, stream);
   return SIHL_EARG;
@@ -1025,6 +1073,16 @@ int sihl_conv2d_dgrad(const void* dout, const void* wt_t, void* din, int N, int 
 int sihl_conv2d_dgrad_ws(const void* dout, const void* wt_t, void* din, const void* add, int N, int H, int W, int Cin,
                          int Cout, int KH, int KW, int stride, int pad, int dil, int dtype, void* ws, long ws_bytes,
                          hipStream_t stream) {
+  return sihl_conv2d_dgrad_add(dout, wt_t, din, add, 1, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, dtype, ws, ws_bytes,
+                               stream);
+}
+
+// sihl_conv2d_dgrad_ws whose addend may be the COMPACT input gradient of a stride-`add_stride` 1x1 projection of the
+// same input ([N][ceil(H/s)][ceil(W/s)][Cin]): it is added at the pixels that projection reads, nothing elsewhere.
+int sihl_conv2d_dgrad_add(const void* dout, const void* wt_t, void* din, const void* add, int add_stride, int N, int H,
+                          int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, int dtype, void* ws,
+                          long ws_bytes, hipStream_t stream) {
+  if (add_stride < 1 || (add_stride > 1 && Cin % (dtype == SIHL_BF16 ? 8 : 4) != 0)) return SIHL_EARG;
   if (!dout || !wt_t || !din || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 ||
       stride <= 0 || dil <= 0 || pad < 0)
     return SIHL_EARG;
@@ -1051,6 +1109,8 @@ int sihl_conv2d_dgrad_ws(const void* dout, const void* wt_t, void* din, const vo
   p.out_image_stride = (long)H * W * Cin;
   p.splits = 1; p.partial = (float*)ws; p.partial_bytes = ws ? ws_bytes : 0;
   p.add = add;
+  p.add_stride = add ? add_stride : 1;
+  p.add_H = (H + add_stride - 1) / add_stride; p.add_W = (W + add_stride - 1) / add_stride;
   if (dtype == SIHL_F32) return dispatch<float>(p, stream);
   if (dtype == SIHL_BF16) return dispatch<bf16_t>(p, stream);
   return SIHL_EARG;

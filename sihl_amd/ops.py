@@ -417,13 +417,16 @@ class ConvBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, cfg, residual=None, hand_over=None,
-                take_over=None):
+                take_over=None, dx_to=None):
         stride, pad, dil, act, order, has_norm, training, eps, momentum, need_grad = cfg
         xd = x.detach()
         ctx.has_res = residual is not None
         # GradCarrier protocol of an identity residual block: the merge (hand_over) parks the identity branch's
         # gradient instead of returning it, the block's first conv (take_over) adds it inside its dgrad epilogue
         ctx.hand_over, ctx.take_over = hand_over, take_over
+        # projection (downsample) conv of a residual block: its input gradient is parked COMPACT in the carrier and the
+        # block's first conv adds it at the pixels the projection reads (sihl_conv2d_dgrad_add)
+        ctx.dx_to = dx_to
         prep = prepared(weight, xd.dtype)
         w = prep.w if prep is not None else weight_khwc(weight, xd.dtype)
         ctx.wt = prep.wt if prep is not None else None  # dgrad operand, valid until the next optimizer step
@@ -502,7 +505,21 @@ class ConvBlockFn(torch.autograd.Function):
         dw = dx = None
         if ctx.needs_input_grad[1]:
             dw = conv2d_wgrad_raw(x, dz, KH, KW, stride, pad, dil).permute(0, 3, 1, 2)  # (O,I,KH,KW) view
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.dx_to is not None and ctx.dx_to.tensor is None:
+            # 1x1, pad 0, stride s: dx is W^T dz at the pixels the conv reads and zero elsewhere - compute it at dz's
+            # resolution (a dense stride-1 1x1 dgrad over the Ho x Wo grid) and hand it over
+            wt = ctx.wt if ctx.wt is not None else weight_for_dgrad(w, flip=True)
+            N, Ho, Wo, Cout = dz.shape
+            Cin = x.shape[-1]
+            dxs = torch.empty((N, Ho, Wo, Cin), dtype=x.dtype, device=x.device)
+            lib = _C.lib()
+            ws_bytes = lib.sihl_conv2d_ws_bytes(N, Ho, Wo, Cout, Cin, 1, 1, 1, 0, 1)
+            ws = workspace(ws_bytes, x.device) if ws_bytes else None
+            rc = lib.sihl_conv2d_dgrad_ws(_p(dz), _p(wt), _p(dxs), None, N, Ho, Wo, Cin, Cout, 1, 1, 1, 0, 1, _dt(x),
+                                          _p(ws), ws.numel() if ws is not None else 0, _stream())
+            check(rc, "sihl_conv2d_dgrad (compact projection gradient)")
+            ctx.dx_to.tensor, ctx.dx_to.stride = dxs, stride
+        elif ctx.needs_input_grad[0]:
             wt = ctx.wt if ctx.wt is not None else weight_for_dgrad(w, flip=True)
             dx = torch.empty_like(x)
             N, H, W, Cin = x.shape
@@ -510,14 +527,20 @@ class ConvBlockFn(torch.autograd.Function):
             ws_bytes = lib.sihl_conv2d_ws_bytes(N, H, W, w.shape[0], Cin, KH, KW, 1, dil * (KH - 1) - pad, dil) \
                 if stride == 1 else 0
             ws = workspace(ws_bytes, x.device) if ws_bytes else None
-            add = None
+            add, add_stride = None, 1
+            if ctx.take_over is not None and ctx.take_over.expect and ctx.take_over.tensor is None:
+                raise RuntimeError("GradCarrier: the shortcut gradient was not parked before the first conv's backward "
+                                   "(the producer must be created after the consumer in forward)")
             if ctx.take_over is not None and ctx.take_over.tensor is not None:
                 add, ctx.take_over.tensor = ctx.take_over.tensor.contiguous(), None
-                assert add.shape == dx.shape and add.dtype == dx.dtype
-            rc = lib.sihl_conv2d_dgrad_ws(_p(dz), _p(wt), _p(dx), _p(add), N, H, W, Cin, w.shape[0], KH, KW, stride,
-                                          pad, dil, _dt(x), _p(ws), ws.numel() if ws is not None else 0, _stream())
+                add_stride, ctx.take_over.stride, ctx.take_over.expect = ctx.take_over.stride, 1, False
+                want = (N, (H + add_stride - 1) // add_stride, (W + add_stride - 1) // add_stride, Cin)
+                assert tuple(add.shape) == want and add.dtype == dx.dtype, (tuple(add.shape), want)
+            rc = lib.sihl_conv2d_dgrad_add(_p(dz), _p(wt), _p(dx), _p(add), add_stride, N, H, W, Cin, w.shape[0], KH, KW,
+                                           stride, pad, dil, _dt(x), _p(ws), ws.numel() if ws is not None else 0,
+                                           _stream())
             check(rc, "sihl_conv2d_dgrad")
-        return dx, dw, dbias, dgamma, dbeta, None, None, None, dres, None, None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, dres, None, None, None
 
 
 class GradCarrier:
@@ -525,18 +548,22 @@ class GradCarrier:
     it in its dgrad epilogue (autograd would otherwise launch one add kernel per block over the block-input tensor:
     1.3 ms per ResNet50 step).  Valid only when both convs read the SAME tensor x: the merge with
     ``residual=x, hand_over=c``, the first conv with ``take_over=c``."""
-    __slots__ = ("tensor", "armed")
+    __slots__ = ("tensor", "armed", "stride", "expect")
 
     def __init__(self):
         self.tensor = None
         self.armed = False  # set once the first conv has agreed to take the gradient over
+        self.stride = 1  # > 1: the parked tensor is the compact input gradient of a strided 1x1 projection (dx_to)
+        self.expect = False  # a producer (hand_over / dx_to) has committed to park a gradient in this backward
 
 
 def conv_block(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, *, stride=1, pad=0, dil=1, act=None,
                order="act_norm", training=False, eps=1e-5, momentum=0.1, residual=None, hand_over=None,
-               take_over=None):
+               take_over=None, dx_to=None):
     """residual (optional, order "norm_act" only): the block computes relu(BN(conv(x)) + residual).
-    hand_over / take_over: see GradCarrier (training only)."""
+    hand_over / take_over: see GradCarrier (training only).  dx_to: carrier that receives this (1x1, pad 0) conv's
+    input gradient in compact form - the projection shortcut of a residual block whose first conv was given the same
+    carrier as take_over and reads the same x."""
     has_norm = running_mean is not None
     # autograd.Function.forward always runs with grad mode off, so decide here whether a backward can follow
     need_grad = torch.is_grad_enabled() and any(
@@ -547,6 +574,11 @@ def conv_block(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, *, 
             take_over.armed = True
             return ConvBlockFn.apply(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, cfg, None, None,
                                      take_over)
+        if dx_to is not None and dx_to.armed and need_grad and x_nhwc.requires_grad and pad == 0 and dil == 1 \
+                and tuple(weight.shape[2:]) == (1, 1) and x_nhwc.shape[-1] % (8 if x_nhwc.dtype == torch.bfloat16 else 4) == 0:
+            dx_to.expect = True
+            return ConvBlockFn.apply(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, cfg, None, None,
+                                     None, dx_to)
         return ConvBlockFn.apply(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, cfg)
     if order != "norm_act" or not has_norm or act is not None:
         raise ValueError("residual merge is defined for conv -> BatchNorm (no activation) blocks")
@@ -555,6 +587,8 @@ def conv_block(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, *, 
         cfg = (stride, pad, dil, act, order, has_norm, training, eps, momentum, need_grad)
         if hand_over is not None and not hand_over.armed:
             hand_over = None  # nobody will pick the gradient up: let autograd route it
+        if hand_over is not None:
+            hand_over.expect = True
         return ConvBlockFn.apply(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, cfg, residual, hand_over)
     return add_relu(ConvBlockFn.apply(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, cfg), residual)
 

@@ -302,3 +302,41 @@ def test_conv_splitk_matches_single_pass(shape, dtype, tol):
         torch.testing.assert_close(y.float(), ref, rtol=rtol, atol=rtol * float(ref.abs().max()))
         torch.testing.assert_close(stats[:, 0].sum(0), ref.reshape(-1, Cout).sum(0), rtol=rtol, atol=rtol * float(ref.abs().sum(0).max()))
     torch.testing.assert_close(outs[1][1].sum(0), outs[0][1].sum(0), rtol=1e-3, atol=1e-3 * float(outs[0][1].abs().max()))
+
+
+@pytest.mark.parametrize("dtype,rtol,atol", DTYPES)
+@pytest.mark.parametrize("shape", [
+    (32, 16, 16, 256, 64, 1, 2),   # N, H, W, Cin(x), Cout(conv1), K, stride of the projection: 128x128 single-stage tile (fused addend)
+    (2, 9, 7, 64, 32, 1, 2),       # odd sizes, ceil(H/2) addend rows; tiny grid -> split-K finisher / late add
+    (64, 32, 32, 256, 256, 1, 2),  # 65536 pixels: the 256x256 tile's fused addend epilogue
+    (2, 8, 8, 32, 32, 3, 2),       # 3x3 consumer
+    (2, 8, 8, 64, 32, 1, 1),       # dense addend (identity-block form) through the same entry point
+])
+def test_dgrad_with_compact_strided_addend(dtype, rtol, atol, shape):
+    """sihl_conv2d_dgrad_add: dx = dgrad(conv1) + the compact input gradient of a stride-s 1x1 projection of the same x,
+    scattered to the pixels that projection reads - against the sum of the two PyTorch input gradients."""
+    ops = _ops()
+    from sihl_amd import _C
+    N, H, W, Cin, Cout, K, s = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, Cin, H, W, generator=g).to(dtype).float().requires_grad_(True)
+    w1 = (torch.randn(Cout, Cin, K, K, generator=g) * 0.1).to(dtype).float()
+    dy = torch.randn(N, Cout, H, W, generator=g).to(dtype).float()
+    Hc, Wc = (H + s - 1) // s, (W + s - 1) // s
+    addc = torch.randn(N, Cin, Hc, Wc, generator=g).to(dtype).float()   # compact projection gradient
+    F.conv2d(x, w1, None, stride=1, padding=K // 2).backward(dy)
+    ref = x.grad.clone()
+    ref[:, :, ::s, ::s] += addc
+    dyd = dy.to(DEV, dtype).permute(0, 2, 3, 1).contiguous()
+    wd = w1.to(DEV, dtype).permute(0, 2, 3, 1).contiguous()
+    wt = ops.weight_for_dgrad(wd, flip=True)
+    addd = addc.to(DEV, dtype).permute(0, 2, 3, 1).contiguous()
+    dx = torch.empty((N, H, W, Cin), device=DEV, dtype=dtype)
+    lib = _C.lib()
+    nbytes = lib.sihl_conv2d_ws_bytes(N, H, W, Cout, Cin, K, K, 1, K // 2, 1)
+    ws = ops.workspace(nbytes, dx.device) if nbytes else None
+    rc = lib.sihl_conv2d_dgrad_add(ops._p(dyd), ops._p(wt), ops._p(dx), ops._p(addd), s, N, H, W, Cin, Cout, K, K, 1, K // 2,
+                                   1, ops._dt(dx), ops._p(ws), ws.numel() if ws is not None else 0, ops._stream())
+    assert rc == 0
+    # the bf16 reference rounds once (sum in fp32); the kernel adds in fp32 before its single rounding as well
+    _close(dx.permute(0, 3, 1, 2), ref, rtol, atol, "dgrad + strided addend")
