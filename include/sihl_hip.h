@@ -183,6 +183,13 @@ int sihl_resize_bilinear_bwd(const void* dout, void* da, int N, int H, int W, in
  * out = act(a + b), act none or relu; backward = sihl_affine_act_bwd(out, dout, relu) for both inputs. */
 int sihl_add_act(const void* a, const void* b, void* out, long numel, int act, int dtype, hipStream_t stream);
 
+/* nn.MaxPool2d(3, 2, 1) of the ResNet stem (torchvision_backbone.py:135-138 via torchvision's resnet) on NHWC tensors:
+ * y [N][Ho][Wo][C], Ho = (H-1)/2 + 1; idx = one byte per output element (winning tap 0..8, first maximum in row-major
+ * window order, NaN wins) consumed by the backward, which gathers per input pixel (no atomics). */
+int sihl_maxpool3x3s2_fwd(const void* x, void* y, void* idx, int N, int H, int W, int C, int dtype, hipStream_t stream);
+int sihl_maxpool3x3s2_bwd(const void* dy, const void* idx, void* dx, int N, int H, int W, int C, int dtype,
+                          hipStream_t stream);
+
 /* ---- MLP hidden layers: y = act(LayerNorm(z)*gamma + beta) over [rows][C] (object_detection.py:51-61) ----- */
 int sihl_layernorm_act(const void* z, void* y, long rows, int C, const float* gamma, const float* beta, float eps,
                        int act, float* mean, float* rstd, int dtype, hipStream_t stream);

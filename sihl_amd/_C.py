@@ -51,6 +51,8 @@ SIGNATURES = {
     "sihl_resize_bilinear": (I, [P, P, P, I, I, I, I, I, I, I, P]),
     "sihl_resize_bilinear_bwd": (I, [P, P, I, I, I, I, I, I, I, P]),
     "sihl_add_act": (I, [P, P, P, L, I, I, P]),
+    "sihl_maxpool3x3s2_fwd": (I, [P, P, P, I, I, I, I, I, P]),
+    "sihl_maxpool3x3s2_bwd": (I, [P, P, P, I, I, I, I, I, P]),
     "sihl_fuse_sum": (I, [P, P, P, P, P, L, I, I, P]),
     "sihl_fuse_sum_bwd": (I, [P, P, P, P, P, P, P, P, P, P, L, I, I, P]),
     "sihl_blur_fuse": (I, [P, P, P, P, P, I, I, I, I, I, P]),

@@ -146,9 +146,15 @@ class _Trunk(nn.Module):
 
     def forward(self, x: Tensor, n_taps: int, native: bool = False) -> List[Tensor]:
         taps = [self.relu(self.bn1(self.conv1(x)))]
-        y = self.maxpool(taps[0])
-        if native:
-            y = ops.nhwc(y)  # a view: the stem runs channels_last
+        vec = 8 if taps[0].dtype == torch.bfloat16 else 4
+        if native and taps[0].dtype in (torch.bfloat16, torch.float32) and taps[0].shape[1] % vec == 0 \
+                and (self.maxpool.kernel_size, self.maxpool.stride, self.maxpool.padding) == (3, 2, 1) \
+                and not os.environ.get("SIHL_ATEN_MAXPOOL"):  # env: A/B switch
+            y = ops.maxpool3x3s2(ops.nhwc(taps[0]))  # NHWC in (a view: the stem runs channels_last), NHWC out
+        else:
+            y = self.maxpool(taps[0])
+            if native:
+                y = ops.nhwc(y)
         for i in range(1, 5):
             if len(taps) >= n_taps:
                 break

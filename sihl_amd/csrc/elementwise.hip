@@ -1174,6 +1174,103 @@ __global__ void weight_prepare_t_kernel(const WeightDesc* __restrict__ descs, in
   }
 }
 
+
+// ---- 3x3 / stride 2 / pad 1 max pooling, NHWC (the ResNet stem's pool).  Forward keeps the winning tap (0..8, first
+// maximum in row-major window order, NaN wins - ATen's rule) as one byte per element; backward is a gather: every
+// INPUT pixel sums the output gradients of the <= 4 windows that picked it (no atomics, one pass, deterministic).
+template <typename T>
+__global__ void maxpool3x3s2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, unsigned char* __restrict__ idx,
+                                        long nvec, int H, int W, int Ho, int Wo, int cv) {
+  constexpr int V = 16 / (int)sizeof(T);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv);
+    long pix = i / cv;
+    const int ox = (int)(pix % Wo); pix /= Wo;
+    const int oy = (int)(pix % Ho);
+    const long n = pix / Ho;
+    // all nine loads are issued together from clamped addresses (branches around them serialised the round trips)
+    uint4 raw[9];
+    bool ok[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int iy = 2 * oy - 1 + k / 3, ix = 2 * ox - 1 + k % 3;
+      ok[k] = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const int iyc = min(max(iy, 0), H - 1), ixc = min(max(ix, 0), W - 1);
+      raw[k] = *(const uint4*)(x + (((n * H + iyc) * W + ixc) * (long)cv + c) * V);
+    }
+    float best[V];
+    int arg[V];
+    bool first = true;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      float v[V];
+      unpack16(raw[k], v, T());
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const bool take = ok[k] && (first || v[e] > best[e] || v[e] != v[e]);
+        best[e] = take ? v[e] : (first ? 0.f : best[e]);
+        arg[e] = take ? k : (first ? 0 : arg[e]);
+      }
+      first = first && !ok[k];
+    }
+    *(uint4*)(y + i * V) = pack16(best, T());
+    unsigned char* ip = idx + i * V;
+    if (V == 8) {
+      uint2 w;
+      w.x = (unsigned)arg[0] | ((unsigned)arg[1] << 8) | ((unsigned)arg[2] << 16) | ((unsigned)arg[3] << 24);
+      w.y = (unsigned)arg[4 % V] | ((unsigned)arg[5 % V] << 8) | ((unsigned)arg[6 % V] << 16) | ((unsigned)arg[7 % V] << 24);
+      *(uint2*)ip = w;
+    } else {
+      *(unsigned*)ip = (unsigned)arg[0] | ((unsigned)arg[1] << 8) | ((unsigned)arg[2] << 16) | ((unsigned)arg[3] << 24);
+    }
+  }
+}
+
+template <typename T>
+__global__ void maxpool3x3s2_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx, T* __restrict__ dx,
+                                        long nvec, int H, int W, int Ho, int Wo, int cv) {
+  constexpr int V = 16 / (int)sizeof(T);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv);
+    long pix = i / cv;
+    const int ix = (int)(pix % W); pix /= W;
+    const int iy = (int)(pix % H);
+    const long n = pix / H;
+    // windows (oy, ox) with 2*oy - 1 <= iy <= 2*oy + 1: oy in {iy/2, (iy+1)/2} (one window for even iy); the four
+    // candidates are loaded together from clamped addresses and masked afterwards
+    uint4 g4[4];
+    unsigned w0[4], w1[4];
+    int kk[4];
+    bool ok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int a = q >> 1, b = q & 1;
+      const int oy = (iy + a) >> 1, ox = (ix + b) >> 1;
+      ok[q] = oy < Ho && ox < Wo && !(a == 1 && !(iy & 1)) && !(b == 1 && !(ix & 1));
+      kk[q] = (iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1));
+      const long o = (((n * Ho + min(oy, Ho - 1)) * Wo + min(ox, Wo - 1)) * (long)cv + c);
+      g4[q] = *(const uint4*)(dy + o * V);
+      const unsigned char* ip = idx + o * V;
+      if (V == 8) { const uint2 w = *(const uint2*)ip; w0[q] = w.x; w1[q] = w.y; }
+      else { w0[q] = *(const unsigned*)ip; w1[q] = 0; }
+    }
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float g[V];
+      unpack16(g4[q], g, T());
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const unsigned t = ((e < 4 ? w0[q] : w1[q]) >> (8 * (e & 3))) & 0xffu;
+        acc[e] += (ok[q] && (int)t == kk[q]) ? g[e] : 0.f;
+      }
+    }
+    *(uint4*)(dx + i * V) = pack16(acc, T());
+  }
+}
+
 }  // namespace
 
 #define SIHL_AFF(A, F) hipLaunchKernelGGL((affine_act_kernel<T, A, F>), dim3(g), dim3(TPB), 0, stream, (const T*)x, (T*)y, nvec, C / V, scale, shift, (const T*)res)
@@ -1350,6 +1447,38 @@ int sihl_resize_bilinear_bwd(const void* dout, void* da, int N, int H, int W, in
     if (C % V) return SIHL_EARG;
     hipLaunchKernelGGL(resize_bilinear_adjoint_kernel<T>, dim3(grid_for((long)N * H * W * (C / V))), dim3(TPB), 0,
                        stream, (const T*)dout, (T*)da, N, H, W, Ho, Wo, C);
+  });
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+// 3x3 / stride 2 / pad 1 max pooling over NHWC x [N][H][W][C] -> y [N][Ho][Wo][C], Ho = (H - 1) / 2 + 1; idx (one byte
+// per output element) receives the winning tap for sihl_maxpool3x3s2_bwd.  C % (16 / sizeof(T)) == 0.
+int sihl_maxpool3x3s2_fwd(const void* x, void* y, void* idx, int N, int H, int W, int C, int dtype, hipStream_t stream) {
+  if (!x || !y || !idx || N <= 0 || H <= 0 || W <= 0 || C <= 0) return SIHL_EARG;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  DISPATCH_DTYPE(dtype, {
+    constexpr int V = 16 / sizeof(T);
+    if (C % V) return SIHL_EARG;
+    const long nvec = (long)N * Ho * Wo * (C / V);
+    hipLaunchKernelGGL((maxpool3x3s2_fwd_kernel<T>), dim3(grid_for(nvec)), dim3(TPB), 0, stream, (const T*)x, (T*)y,
+                       (unsigned char*)idx, nvec, H, W, Ho, Wo, C / V);
+  });
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+// dx [N][H][W][C] of sihl_maxpool3x3s2_fwd from dy [N][Ho][Wo][C] and the forward's idx (every element written).
+int sihl_maxpool3x3s2_bwd(const void* dy, const void* idx, void* dx, int N, int H, int W, int C, int dtype,
+                          hipStream_t stream) {
+  if (!dy || !idx || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0) return SIHL_EARG;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  DISPATCH_DTYPE(dtype, {
+    constexpr int V = 16 / sizeof(T);
+    if (C % V) return SIHL_EARG;
+    const long nvec = (long)N * H * W * (C / V);
+    hipLaunchKernelGGL((maxpool3x3s2_bwd_kernel<T>), dim3(grid_for(nvec)), dim3(TPB), 0, stream, (const T*)dy,
+                       (const unsigned char*)idx, (T*)dx, nvec, H, W, Ho, Wo, C / V);
   });
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;

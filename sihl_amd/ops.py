@@ -1067,3 +1067,37 @@ class AddReluFn(torch.autograd.Function):
 
 def add_relu(a, b):
     return AddReluFn.apply(a, b)
+
+
+class MaxPool3x3s2Fn(torch.autograd.Function):
+    """nn.MaxPool2d(3, 2, 1) on an NHWC tensor (the ResNet stem's pool).  Forward stores the winning tap per element
+    (one byte); backward gathers per input pixel - one pass, no atomics (ATen's NHWC backward: 406 us at bs 32, 256^2
+    x 64; this pair: see profiles)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        xd = x.detach().contiguous()
+        N, H, W, C = xd.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((N, Ho, Wo, C), dtype=xd.dtype, device=xd.device)
+        idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=xd.device)
+        rc = _C.lib().sihl_maxpool3x3s2_fwd(_p(xd), _p(y), _p(idx), N, H, W, C, _dt(xd), _stream())
+        check(rc, "sihl_maxpool3x3s2_fwd")
+        ctx.save_for_backward(idx)
+        ctx.in_shape = (N, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        N, H, W, C = ctx.in_shape
+        dy = dy.contiguous()
+        dx = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
+        rc = _C.lib().sihl_maxpool3x3s2_bwd(_p(dy), _p(idx), _p(dx), N, H, W, C, _dt(dy), _stream())
+        check(rc, "sihl_maxpool3x3s2_bwd")
+        return dx
+
+
+def maxpool3x3s2(x_nhwc: Tensor) -> Tensor:
+    return MaxPool3x3s2Fn.apply(x_nhwc)

@@ -340,3 +340,24 @@ def test_dgrad_with_compact_strided_addend(dtype, rtol, atol, shape):
     assert rc == 0
     # the bf16 reference rounds once (sum in fp32); the kernel adds in fp32 before its single rounding as well
     _close(dx.permute(0, 3, 1, 2), ref, rtol, atol, "dgrad + strided addend")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64), (3, 7, 9, 8), (1, 1, 1, 8), (2, 2, 3, 16), (4, 64, 64, 64)])
+def test_maxpool3x3s2_matches_torch(dtype, shape):
+    """nn.MaxPool2d(3, 2, 1): outputs equal bit for bit (a maximum is exact), input gradients equal to the sum order of
+    at most four window gradients (odd sizes, 1x1 maps and ties after a ReLU included)."""
+    ops = _ops()
+    N, H, W, C = shape
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, C, H, W, generator=g).relu().to(dtype)  # relu: plenty of ties at 0 -> first-maximum rule matters
+    xr = x.float().clone().requires_grad_(True)
+    ref = F.max_pool2d(xr, 3, 2, 1)
+    dy = torch.randn(ref.shape, generator=g).to(dtype)
+    ref.backward(dy.float())
+    xd = x.to(DEV).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+    y = ops.maxpool3x3s2(xd)
+    y.backward(dy.to(DEV).permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(y.detach().permute(0, 3, 1, 2).float().cpu(), ref.detach())
+    tol = 1e-6 if dtype == torch.float32 else 2e-2
+    _close(xd.grad.permute(0, 3, 1, 2), xr.grad, tol, tol, "maxpool dx")
