@@ -55,6 +55,7 @@ int sihl_conv2d_tile_override(int bm);
 int sihl_conv2d_nbuf_override(int n); /* tuning hook: LDS stages of the narrow-tile kernels, 0 = default */
 /* Tuning ablation of the LDS-DMA kernel (results are INVALID when non-zero): 1 = no in-loop DMA, 2 = no ds_read/MFMA. */
 int sihl_conv2d_debug(int mode);
+int sihl_conv2d_strided_classes_enable(int on); /* test hook: 0 = zero-dilated read for 3x3 stride-2 dgrads */
 int sihl_conv2d_fwd(const void* in, const void* wt, const float* bias, void* out, int N, int H, int W, int Cin,
                     int Cout, int KH, int KW, int stride, int pad, int dil, int dtype, int act,
                     const float* pre_scale, const float* pre_shift, const float* post_scale,

@@ -23,6 +23,7 @@ SIGNATURES = {
     "sihl_conv2d_tile_override": (I, [I]),
     "sihl_conv2d_nbuf_override": (I, [I]),
     "sihl_conv2d_debug": (I, [I]),
+    "sihl_conv2d_strided_classes_enable": (I, [I]),
     "sihl_conv2d_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, P, P, P, I, P, L, L, P]),
     "sihl_conv2d_dgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "sihl_conv2d_ws_bytes": (L, [I, I, I, I, I, I, I, I, I, I]),

@@ -45,6 +45,11 @@ struct ConvParams {
   long partial_bytes;
   const void* add;  // optional tensor of the output's shape added in the epilogue (dense output only): the identity
                     // branch's gradient riding on a residual block's first dgrad instead of a separate add kernel
+  // Parity classes of a strided conv's dgrad (sihl_conv2d_dgrad_add, LDS-DMA kernel only): the launch walks a KHxKW
+  // SUBSET of a w_kh x w_kw weight window - window tap (ky, kx) multiplies weight tap (w_ky0 + ky*w_kys, w_kx0 +
+  // kx*w_kxs) - and scatters output pixel (i, j) to (i*out_s + out_py, j*out_s + out_px) of an out_W-wide image.
+  int w_ntaps, w_kw, w_ky0, w_kys, w_kx0, w_kxs;  // defaults: KH*KW, KW, 0, 1, 0, 1
+  int out_s, out_py, out_px, out_W;                // defaults: 1, 0, 0, Wo
   int add_stride;   // > 1: the addend is [N][add_H][add_W][Cout] and lands on output pixels (y, x) with y % add_stride
   int add_H, add_W; // == 0 and x % add_stride == 0 only (input gradient of a strided 1x1 projection: zero elsewhere)
 };
@@ -64,6 +69,7 @@ int g_dbg = 0;
 int g_tile_override = 0;    // test / tuning hook: 0 = heuristic, 128 / 256 = force that pixel-tile size
 int g_nbuf = 0;             // tuning hook: LDS stages of the narrow LDS-DMA tiles (0 = default)
 bool g_splitk = true;       // tuning / test hook: split-K for tiny pyramid levels
+bool g_strided_classes = true;  // tuning / test hook: parity-class dgrad of 3x3 stride-2 convs (else zero-dilated read)
 int g_rules_off = 0;        // tuning hook: bit 0 = no single-stage narrow tiles, bit 1 = no 128x128 routing of thin pointwise layers
 
 constexpr int BM128 = 128;
@@ -198,7 +204,12 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t
     if (m >= p.M || co >= p.Cout) continue;
     const char* src = epi + row * EPI_STRIDE + ch * 16;
     const int n_img = m / hw_o;
-    T* dst = out + (long)n_img * p.out_image_stride + (long)(m - n_img * hw_o) * p.Cout + co;
+    long pix = m - n_img * hw_o;
+    if (p.out_s > 1) {  // parity class of a strided dgrad: (i, j) -> (i*s + py, j*s + px)
+      const int i = (int)pix / p.Wo, j = (int)pix - i * p.Wo;
+      pix = (long)(i * p.out_s + p.out_py) * p.out_W + j * p.out_s + p.out_px;
+    }
+    T* dst = out + (long)n_img * p.out_image_stride + pix * p.Cout + co;
     if (vec_ok && co + VEC <= p.Cout) {
       *(uint4*)dst = *(const uint4*)src;
     } else {
@@ -399,7 +410,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(const Conv
   const int nstages = min(total_stages, s_first + per_split) - s_first;
 
   const v4i_t in_rsrc = make_rsrc(p.in, (unsigned)((long)p.N * p.H * p.W * p.Cin * (long)sizeof(T)));
-  const v4i_t wt_rsrc = make_rsrc(p.wt, (unsigned)((long)p.Cout * ntaps * p.Cin * (long)sizeof(T)));
+  const v4i_t wt_rsrc = make_rsrc(p.wt, (unsigned)((long)p.Cout * p.w_ntaps * p.Cin * (long)sizeof(T)));
   const unsigned lds_base = (unsigned)(unsigned long)(lds_ptr_t)smem;
 
   // ---- per-thread slot geometry (fixed for the whole K loop).  Per K stage only a scalar delta is added:
@@ -452,7 +463,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(const Conv
     const int q = (wave * NBL + j) * 64 + lane, row = q >> 3, pos = q & 7;
     b_ch[j] = (pos ^ ((row >> 1) & 7)) * VEC;
     const int co = n0 + row;
-    b_off[j] = co < p.Cout ? (unsigned)(((long)co * ntaps * p.Cin + b_ch[j]) * (long)sizeof(T)) : 0x80000000u;
+    b_off[j] = co < p.Cout ? (unsigned)(((long)co * p.w_ntaps * p.Cin + b_ch[j]) * (long)sizeof(T)) : 0x80000000u;
   }
   const bool cin_full = (p.Cin % KCE) == 0;
 
@@ -470,7 +481,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(const Conv
     n_kc = c_kc; n_tap = c_tap; n_ky = c_ky; n_kx = c_kx;
     n_tapbit = 1u << n_tap;
     n_adelta = ((n_ky * p.dil * p.W + n_kx * p.dil) * p.Cin) * (int)sizeof(T) + n_kc * KCB;
-    n_bdelta = n_tap * p.Cin * (int)sizeof(T) + n_kc * KCB;
+    n_bdelta = ((p.w_ky0 + n_ky * p.w_kys) * p.w_kw + p.w_kx0 + n_kx * p.w_kxs) * p.Cin * (int)sizeof(T) + n_kc * KCB;
     n_abase = lds_base + buf * STAGE + wave * NA * 1024;
     n_bbase = lds_base + buf * STAGE + A_BYTES + wave * NBL * 1024;
   };
@@ -829,7 +840,8 @@ int launch_dma(const ConvParams& p0, hipStream_t stream) {
     }
     attr_set = true;
   }
-  const double flops = 2.0 * p.M * (double)p.Cout * p.KH * p.KW * p.Cin;
+  // algorithmic flops: the zero-dilated read of a strided conv's dgrad multiplies (in_dilate^2 - 1) / in_dilate^2 zeros
+  const double flops = 2.0 * p.M * (double)p.Cout * p.KH * p.KW * p.Cin / ((double)p.in_dilate * p.in_dilate);
   const double bytes = ((double)p.N * p.H * p.W * p.Cin + (double)p.M * p.Cout + (double)p.Cout * p.KH * p.KW * p.Cin) * sizeof(T);
   sihl_prof_begin(SIHL_PROF_CONV, sizeof(T) == 2 ? SIHL_BF16 : SIHL_F32, flops, bytes, stream);
   hipLaunchKernelGGL(kern, dim3(p.gridM * p.gridN, p.splits), dim3(WM * WN * 64), LDS, stream, p);
@@ -856,7 +868,8 @@ int launch_reg(const ConvParams& p0, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  const double flops = 2.0 * p.M * (double)p.Cout * p.KH * p.KW * p.Cin;
+  // algorithmic flops: the zero-dilated read of a strided conv's dgrad multiplies (in_dilate^2 - 1) / in_dilate^2 zeros
+  const double flops = 2.0 * p.M * (double)p.Cout * p.KH * p.KW * p.Cin / ((double)p.in_dilate * p.in_dilate);
   const double bytes = ((double)p.N * p.H * p.W * p.Cin + (double)p.M * p.Cout + (double)p.Cout * p.KH * p.KW * p.Cin) * sizeof(T);
   sihl_prof_begin(SIHL_PROF_CONV, sizeof(T) == 2 ? SIHL_BF16 : SIHL_F32, flops, bytes, stream);
   const void* late_add = p.add;
@@ -1009,6 +1022,9 @@ int sihl_conv2d_rules_off(int mask) { g_rules_off = mask; return 0; }
 // Tuning / test hook: 0 disables split-K.
 int sihl_conv2d_splitk_enable(int on) { g_splitk = on != 0; return 0; }
 
+// Tuning / test hook: 0 = strided 3x3 dgrads read a zero-dilated dout (one launch) instead of four parity classes.
+int sihl_conv2d_strided_classes_enable(int on) { g_strided_classes = on != 0; return 0; }
+
 int sihl_conv2d_fwd(const void* in, const void* wt, const float* bias, void* out, int N, int H, int W, int Cin,
                     int Cout, int KH, int KW, int stride, int pad, int dil, int dtype, int act,
                     const float* pre_scale, const float* pre_shift, const float* post_scale,
@@ -1054,6 +1070,8 @@ int sihl_conv2d_fwd_ws(const void* in, const void* wt, const float* bias, void* 
   }
   p.splits = 1; p.partial = (float*)ws; p.partial_bytes = ws ? ws_bytes : 0;
   p.add = nullptr; p.add_stride = 1; p.add_H = p.add_W = 0;
+  p.w_ntaps = KH * KW; p.w_kw = KW; p.w_ky0 = p.w_kx0 = 0; p.w_kys = p.w_kxs = 1;
+  p.out_s = 1; p.out_py = p.out_px = 0; p.out_W = p.Wo;
   if (dtype == SIHL_F32) return dispatch<float>(p, stream);
   if (dtype == SIHL_BF16) return dispatch<bf16_t>(p, stream);
   return SIHL_EARG;
@@ -1111,6 +1129,34 @@ int sihl_conv2d_dgrad_add(const void* dout, const void* wt_t, void* din, const v
   p.add = add;
   p.add_stride = add ? add_stride : 1;
   p.add_H = (H + add_stride - 1) / add_stride; p.add_W = (W + add_stride - 1) / add_stride;
+  p.w_ntaps = KH * KW; p.w_kw = KW; p.w_ky0 = p.w_kx0 = 0; p.w_kys = p.w_kxs = 1;
+  p.out_s = 1; p.out_py = p.out_px = 0; p.out_W = W;
+  // 3x3 / stride 2 / pad 1 (the strided convs of the ResNet stages): four parity classes of output pixels, each a small
+  // dense conv over dout with the 1, 2, 2 or 4 weight taps that meet it (dx[2i+py] = sum_ky dout[(2i+py+1-ky)/2] w[ky]
+  // over the ky that make the index whole: ky = 1 for py = 0; ky = 2 (row i) and ky = 0 (row i+1) for py = 1; in the
+  // flipped dgrad weights that is tap 1, resp. taps 0 and 2) - the same MACs as the forward, where the zero-dilated
+  // read below multiplies 3 zeros out of 4
+  const int vs = dtype == SIHL_BF16 ? 2 : 4;
+  const bool dma_ok = !g_force_reg && (long)N * p.H * p.W * Cout * vs < (1L << 31) && (long)Cin * 9 * Cout * vs < (1L << 31);
+  if (stride == 2 && KH == 3 && KW == 3 && pad == 1 && dil == 1 && !add && dma_ok && g_strided_classes &&
+      Cout % (16 / vs) == 0 && (dtype == SIHL_F32 || dtype == SIHL_BF16)) {
+    for (int py = 0; py < 2; ++py)
+      for (int px = 0; px < 2; ++px) {
+        ConvParams q = p;
+        q.in_dilate = 1;
+        q.pad = 0;
+        q.KH = py ? 2 : 1; q.KW = px ? 2 : 1;
+        q.w_ky0 = py ? 0 : 1; q.w_kys = 2; q.w_kx0 = px ? 0 : 1; q.w_kxs = 2;
+        q.Ho = (H - py + 1) / 2; q.Wo = (W - px + 1) / 2;  // output rows 2i+py < H
+        if (q.Ho <= 0 || q.Wo <= 0) continue;
+        q.M = N * q.Ho * q.Wo;
+        q.out_s = 2; q.out_py = py; q.out_px = px; q.out_W = W;
+        q.partial = nullptr; q.partial_bytes = 0;
+        const int rc = dtype == SIHL_F32 ? dispatch<float>(q, stream) : dispatch<bf16_t>(q, stream);
+        if (rc != SIHL_OK) return rc;
+      }
+    return SIHL_OK;
+  }
   if (dtype == SIHL_F32) return dispatch<float>(p, stream);
   if (dtype == SIHL_BF16) return dispatch<bf16_t>(p, stream);
   return SIHL_EARG;

@@ -30,6 +30,7 @@ CONV_SHAPES = [
     (2, 16, 16, 96, 160, 3, 1, 1),   # ragged channel chunks / Cout tiles
     (2, 16, 16, 32, 32, 3, 2, 1),    # stride 2 (FPN extra levels)
     (2, 15, 17, 32, 64, 3, 2, 1),    # stride 2, odd sizes
+    (4, 32, 32, 128, 128, 3, 2, 1),  # stride 2, ResNet conv2 of a stage's first block (parity-class dgrad, 128x128 tiles)
     (2, 16, 16, 64, 32, 1, 2, 0),    # 1x1 stride 2 (ResNet downsample)
     (1, 1, 300, 256, 8, 1, 1, 0),    # linear head as 1x1 over rows
     (4, 64, 64, 256, 256, 3, 1, 1),  # a real L3-like tile count
