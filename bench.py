@@ -278,7 +278,7 @@ def main():
     # those passes over this same command, not from this run
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bench.json")))["kernels"]["conv_igemm_dma_kernel"]
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_s2_pmc_bench.json")))["kernels"]["conv_igemm_dma_kernel"]
         if args.dtype == "bf16" and args.batch == 32 and args.size == 512:
             traffic = pmc["traffic_MB_per_launch"] * 1e6
     except (OSError, KeyError, ValueError):
@@ -287,7 +287,7 @@ def main():
         achieved = fl.value / (ms.value * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (NHWC implicit-GEMM conv: fwd / dgrad / linear)",
                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                    "traffic_note": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_bench.json); "
+                    "traffic_note": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_s2_pmc_bench.json); "
                                     "algorithmic bytes per launch: avg_algorithmic_mb_per_launch",
                     "avg_algorithmic_mb_per_launch": by.value / n.value / 1e6,
                     "frac_of_per_launch_roofline": per_launch_roofline(0),  # each launch against min(MFMA, HBM) bound
