@@ -25,7 +25,13 @@ def boxes_targets(batch, size, g):
     return {"classes": classes, "boxes": boxes}
 
 
-def run(name, model, images, targets, amp, steps=8, graph=True):
+def run(name, model, images, targets, amp, steps=8):
+    import copy
+    for mode, graph in (("eager two-stream", False), ("HIP-graph single-stream", True)):
+        _run(f"{name} [{mode}]", copy.deepcopy(model), images, targets, amp, steps, graph)
+
+
+def _run(name, model, images, targets, amp, steps, graph):
     tr = Trainer(model, lr=1e-4, weight_decay=1e-4, backbone_lr_factor=0.1, grad_clip_norm=0.1, autocast_dtype=amp, graph=graph)
     for _ in range(4):
         tr.step(images, targets)
