@@ -9,7 +9,8 @@ import os
 from ctypes import c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsihl_hip.so")
+# SIHL_HIP_LIB: developer override (same-box A/B of two builds); the product always loads the in-tree library
+LIB_PATH = os.environ.get("SIHL_HIP_LIB") or os.path.join(_HERE, "libsihl_hip.so")
 
 F32, BF16 = 0, 1
 ACT = {None: 0, "none": 0, "relu": 1, "silu": 2, "sigmoid": 3}
