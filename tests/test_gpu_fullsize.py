@@ -102,3 +102,63 @@ def test_full_batch_properties(dtype):
         one = neck([t[:1] for t in levels])
     for l in range(3, 8):
         assert rel(full[l][:1], one[l]) < tol * 5, l
+
+
+@pytest.mark.parametrize("shape", [(32, 128, 128, 128, 128), (32, 64, 64, 256, 256), (32, 32, 32, 512, 512)])
+def test_strided_dgrad_parity_classes_equal_dilated_read_at_resnet_sizes(shape):
+    """The 3x3 / stride-2 input gradient computed as four parity classes (the shipped path) and through the zero-dilated
+    read of the whole output grid are the same sum of products in a different order: equal to bf16 rounding at the
+    full ResNet50 stage-entry sizes of a 512x512 batch of 32, and every output pixel is written (no parity skipped)."""
+    from sihl_amd import _C, ops
+    N, H, W, Cin, Cout = shape
+    g = torch.Generator(device="cuda").manual_seed(11)
+    dy = torch.randn(N, H // 2, W // 2, Cout, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    wt = ops.weight_for_dgrad(w, flip=True)
+    lib = _C.lib()
+    outs = []
+    for classes in (1, 0):
+        lib.sihl_conv2d_strided_classes_enable(classes)
+        dx = torch.full((N, H, W, Cin), float("nan"), device="cuda", dtype=torch.bfloat16)
+        rc = lib.sihl_conv2d_dgrad(ops._p(dy), ops._p(wt), ops._p(dx), N, H, W, Cin, Cout, 3, 3, 2, 1, 1, ops._dt(dx),
+                                   ops._stream())
+        assert rc == 0
+        outs.append(dx.float())
+    lib.sihl_conv2d_strided_classes_enable(1)
+    a, b = outs
+    assert torch.isfinite(a).all()
+    scale = float(b.abs().max())
+    assert float((a - b).abs().max()) <= 2e-2 * scale
+    assert float((a - b).abs().mean()) <= 2e-3 * scale
+
+
+def test_compact_projection_gradient_equals_dilated_dgrad_plus_add():
+    """ResNet50 layer2 entry at bs 32: conv1's dgrad with the projection's compact gradient added at the strided
+    pixels (sihl_conv2d_dgrad_add) against the two separate input gradients summed by PyTorch."""
+    from sihl_amd import _C, ops
+    N, H, W, Cin, C1, Cds = 32, 128, 128, 256, 128, 512
+    g = torch.Generator(device="cuda").manual_seed(12)
+    dz1 = torch.randn(N, H, W, C1, device="cuda", generator=g).to(torch.bfloat16)            # grad of conv1's output
+    dzd = torch.randn(N, H // 2, W // 2, Cds, device="cuda", generator=g).to(torch.bfloat16)  # grad of the projection's
+    w1 = (torch.randn(C1, 1, 1, Cin, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    wd = (torch.randn(Cds, 1, 1, Cin, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    lib = _C.lib()
+    wt1, wtd = ops.weight_for_dgrad(w1, flip=True), ops.weight_for_dgrad(wd, flip=True)
+    # reference: two plain dgrads (the projection's through the zero-dilated read), summed in fp32
+    d1 = torch.empty((N, H, W, Cin), device="cuda", dtype=torch.bfloat16)
+    d2 = torch.empty_like(d1)
+    assert lib.sihl_conv2d_dgrad(ops._p(dz1), ops._p(wt1), ops._p(d1), N, H, W, Cin, C1, 1, 1, 1, 0, 1, ops._dt(d1),
+                                 ops._stream()) == 0
+    assert lib.sihl_conv2d_dgrad(ops._p(dzd), ops._p(wtd), ops._p(d2), N, H, W, Cin, Cds, 1, 1, 2, 0, 1, ops._dt(d2),
+                                 ops._stream()) == 0
+    ref = d1.float() + d2.float()
+    # shipped path: compact projection gradient, then conv1's dgrad adds it
+    dxs = torch.empty((N, H // 2, W // 2, Cin), device="cuda", dtype=torch.bfloat16)
+    assert lib.sihl_conv2d_dgrad(ops._p(dzd), ops._p(wtd), ops._p(dxs), N, H // 2, W // 2, Cin, Cds, 1, 1, 1, 0, 1,
+                                 ops._dt(dxs), ops._stream()) == 0
+    dx = torch.empty_like(d1)
+    assert lib.sihl_conv2d_dgrad_add(ops._p(dz1), ops._p(wt1), ops._p(dx), ops._p(dxs), 2, N, H, W, Cin, C1, 1, 1, 1, 0, 1,
+                                     ops._dt(dx), None, 0, ops._stream()) == 0
+    scale = float(ref.abs().max())
+    assert float((dx.float() - ref).abs().max()) <= 2e-2 * scale
+    assert float((d2.float()[:, 1::2] ).abs().max()) == 0.0  # the projection contributes nothing off its pixels
