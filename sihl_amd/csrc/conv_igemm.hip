@@ -103,6 +103,41 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t
   float* red = (float*)(smem + BM * EPI_STRIDE);  // [2][WM][BN]
   const int half = lane >> 5;
   const bool has_pre = p.pre_scale != nullptr, has_post = p.post_scale != nullptr;
+  // The element loop is VALU-bound on store-heavy layers (64 elements per lane at ~10 instructions each: a thin
+  // pointwise conv spent more time here than loading, multiplying and storing).  The common training launch - no
+  // affines, every row of the tile inside M - takes a path with the bias, the activation, the statistics and the
+  // conversion only.
+  const bool lean = !has_pre && !has_post && m0 + BM <= p.M;
+  if (lean) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int cl = wn * WTN + j * 32 + (lane & 31);
+      const float bias = (p.bias && n0 + cl < p.Cout) ? p.bias[n0 + cl] : 0.f;
+      float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          float v = acc[i][j][r] + bias;
+          if (STATS == 1) { ssum += v; ssq += v * v; }
+          if (ACT == SIHL_ACT_RELU) v = fmaxf(v, 0.f);
+          else if (ACT == SIHL_ACT_SILU) v = v / (1.f + expf(-v));
+          else if (ACT == SIHL_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+          if (STATS == 2) { ssum += v; ssq += v * v; }
+          elem<T>::st((T*)(epi + row * EPI_STRIDE) + cl, v);
+        }
+      }
+      if (STATS) {
+        ssum += __shfl_xor(ssum, 32);
+        ssq += __shfl_xor(ssq, 32);
+        if (half == 0) {
+          red[(0 * WM + wm) * BN + cl] = ssum;
+          red[(1 * WM + wm) * BN + cl] = ssq;
+        }
+      }
+    }
+  } else
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int cl = wn * WTN + j * 32 + (lane & 31);  // column inside the tile
@@ -195,6 +230,16 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t
         for (int e = 0; e < VEC; ++e) a[e] += c[e];
         *(uint4*)(out + (long)m * p.Cout + co) = pack16(a, T());
       }
+    }
+    return;
+  }
+  if (vec_ok && p.out_s == 1 && p.out_image_stride == (long)hw_o * p.Cout) {
+    // dense output: row m starts at m * Cout (no per-chunk division by the image size)
+    for (int idx = tid; idx < BM * CHUNKS; idx += NTHREADS) {
+      const int row = idx / CHUNKS, ch = idx - row * CHUNKS;
+      const int m = m0 + row, co = n0 + ch * VEC;
+      if (m >= p.M || co + VEC > p.Cout) continue;
+      *(uint4*)(out + (long)m * p.Cout + co) = *(const uint4*)(epi + row * EPI_STRIDE + ch * 16);
     }
     return;
   }
