@@ -15,8 +15,8 @@ small = collections.defaultdict(lambda: [0, 0.0])
 mid = collections.defaultdict(lambda: [0, 0.0])
 tot = 0.0
 for r in sel:
-    wg = max(1, int(r["Workgroup_Size"]))
-    nwg = int(r["Grid_Size"]) // wg
+    wg = max(1, int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"]))
+    nwg = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) // wg
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     tot += d
     key = r["Kernel_Name"][:90]
