@@ -199,6 +199,11 @@ class Trainer:
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         on_gpu = all(p.is_cuda for p in model.parameters())
         self.use_graph = bool(graph) and world == 1 and on_gpu
+        if self.use_graph:
+            # graph mode is single-stream THROUGHOUT, warm-up steps included: two-stream eager warm-up steps followed
+            # by a capture ended in a GPU memory access fault on a later step in every process but the first on a box
+            # (three of three; never with single-stream warm-up, never in eager mode) - cause not isolated this round
+            self.wgrad_stream = "off"
         if self.use_graph and optimizer is None:
             opt_kw.setdefault("capturable", True)  # optimizer step counters live on the device
         self.optimizer = optimizer or configure_optimizer(model, **opt_kw)
