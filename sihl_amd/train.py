@@ -8,6 +8,7 @@ Counterpart of what the reference delegates to Lightning (src/sihl/lightning_mod
   * DP: minibatch sharded across ranks, per-replica BatchNorm statistics (Lightning-DDP default), gradients
     averaged with bucketed all-reduces launched from grad-ready hooks so they overlap the rest of backward.
 """
+import os
 from typing import Any, Dict, List, Optional, Sequence
 
 import torch
@@ -203,7 +204,7 @@ class Trainer:
             # graph mode is single-stream THROUGHOUT, warm-up steps included: two-stream eager warm-up steps followed
             # by a capture ended in a GPU memory access fault on a later step in every process but the first on a box
             # (three of three; never with single-stream warm-up, never in eager mode) - cause not isolated this round
-            self.wgrad_stream = "off"
+            self.wgrad_stream = os.environ.get("SIHL_GRAPH_WARMUP_STREAM", "off")  # env: debugging only
         if self.use_graph and optimizer is None:
             opt_kw.setdefault("capturable", True)  # optimizer step counters live on the device
         self.optimizer = optimizer or configure_optimizer(model, **opt_kw)
@@ -279,6 +280,7 @@ class Trainer:
         head, ~1 ms of small launches at bs 32) compute it on the side stream while the backbone and the neck run.
         Returns the stream to wait for before the heads' training_step, or None."""
         if (self.wgrad_stream == "off" or not images.is_cuda or torch.cuda.is_current_stream_capturing()
+                or os.environ.get("SIHL_NO_PREMATCH")
                 or not any(hasattr(h, "prematch") for h in self.model.heads)):
             return None
         from sihl_amd import ops
