@@ -18,6 +18,7 @@
 // transposed through LDS and written with 16-byte row-contiguous stores; per-channel (sum, sumsq)
 // partials for BatchNorm batch statistics go to a workspace row per M-tile (deterministic, no atomics).
 #include "common.h"
+#include <type_traits>
 #include "dma.h"
 #include "profile.h"
 
@@ -107,36 +108,46 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t
   // pointwise conv spent more time here than loading, multiplying and storing).  The common training launch - no
   // affines, every row of the tile inside M - takes a path with the bias, the activation, the statistics and the
   // conversion only.
-  const bool lean = !has_pre && !has_post && m0 + BM <= p.M;
+  const bool lean = !has_pre && m0 + BM <= p.M;
   if (lean) {
+    // (the post-affine of an inference launch - BatchNorm folded behind the activation - stays: one FMA)
+    auto body = [&](auto post_tag) {
+      constexpr bool POST = decltype(post_tag)::value;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int cl = wn * WTN + j * 32 + (lane & 31);
-      const float bias = (p.bias && n0 + cl < p.Cout) ? p.bias[n0 + cl] : 0.f;
-      float ssum = 0.f, ssq = 0.f;
+      for (int j = 0; j < NT; ++j) {
+        const int cl = wn * WTN + j * 32 + (lane & 31);
+        const bool cok = n0 + cl < p.Cout;
+        const float bias = (p.bias && cok) ? p.bias[n0 + cl] : 0.f;
+        const float s2 = (POST && cok) ? p.post_scale[n0 + cl] : 1.f;
+        const float t2 = (POST && p.post_shift && cok) ? p.post_shift[n0 + cl] : 0.f;
+        float ssum = 0.f, ssq = 0.f;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
+        for (int i = 0; i < MT; ++i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          float v = acc[i][j][r] + bias;
-          if (STATS == 1) { ssum += v; ssq += v * v; }
-          if (ACT == SIHL_ACT_RELU) v = fmaxf(v, 0.f);
-          else if (ACT == SIHL_ACT_SILU) v = v / (1.f + expf(-v));
-          else if (ACT == SIHL_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
-          if (STATS == 2) { ssum += v; ssq += v * v; }
-          elem<T>::st((T*)(epi + row * EPI_STRIDE) + cl, v);
+          for (int r = 0; r < 16; ++r) {
+            const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = acc[i][j][r] + bias;
+            if (STATS == 1) { ssum += v; ssq += v * v; }
+            if (ACT == SIHL_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (ACT == SIHL_ACT_SILU) v = v / (1.f + expf(-v));
+            else if (ACT == SIHL_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+            if (STATS == 2) { ssum += v; ssq += v * v; }
+            if (POST) v = v * s2 + t2;
+            elem<T>::st((T*)(epi + row * EPI_STRIDE) + cl, v);
+          }
+        }
+        if (STATS) {
+          ssum += __shfl_xor(ssum, 32);
+          ssq += __shfl_xor(ssq, 32);
+          if (half == 0) {
+            red[(0 * WM + wm) * BN + cl] = ssum;
+            red[(1 * WM + wm) * BN + cl] = ssq;
+          }
         }
       }
-      if (STATS) {
-        ssum += __shfl_xor(ssum, 32);
-        ssq += __shfl_xor(ssq, 32);
-        if (half == 0) {
-          red[(0 * WM + wm) * BN + cl] = ssum;
-          red[(1 * WM + wm) * BN + cl] = ssq;
-        }
-      }
-    }
+    };
+    if (has_post) body(std::true_type{});
+    else body(std::false_type{});
   } else
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
