@@ -135,6 +135,22 @@ def north_star_forward(model, device, dtype, batch, size, iters=20):
             "frac_of_hbm_roofline": mbytes / ms / 8000.0, "bound": "mfma (AI 520 flop/B against a ridge of ~310)"}
 
 
+def self_launch(n):
+    """Start `n` ranks of this script under torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) as a child
+    process and wait for it.  The caller must not have initialised the GPU: nothing is re-executed in place."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", str(max(1, usable_cores() // n))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,13 +181,31 @@ def main():
     ap.add_argument("--rehearse-dp", action="store_true",
                     help="N=1 only: run the multi-GPU code path (process group of one rank, gradient buckets, hooks, "
                          "all-reduce calls on the collective's stream) on a single GPU")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous only (no GPU work): every rank joins the process group, rank 0 prints the number "
+                         "of ranks seen - the CPU test of the self-launcher")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # bare `python bench.py --gpus N`: this process has not touched the GPU (no torch.cuda call so far) and never
+        # will - it starts N fresh ranks, lets rank 0's JSON line through on the inherited stdout and exits with
+        # the launcher's return code (non-zero as soon as any rank fails)
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.launch_check:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        seen = torch.ones(1)
+        dist.all_reduce(seen)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": int(seen.item())}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the hot path has no CPU fallback)")
     dev_index = 0 if args.same_device else local_rank
@@ -248,9 +282,12 @@ def main():
         trace("north-star forward probe done")
 
     t = torch.tensor([dt], device=device, dtype=torch.float64)
+    seen = torch.ones(1, device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(seen)
     dt = float(t.item())
+    ranks_seen = int(seen.item())
 
     # roofline of the dominant kernel: matrix-core conv (forward / dgrad / linear launches)
     dt_code = _C.BF16 if args.dtype == "bf16" else _C.F32
@@ -304,7 +341,7 @@ def main():
     if rank == 0:
         out = {
             "metric": METRIC, "value": args.batch * world * args.steps / dt, "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": n_warm, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": n_warm, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "ResNet50 + BiFPN(3-7,256ch,3 layers) + ObjectDetection(80 cls) training step: "

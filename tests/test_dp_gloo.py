@@ -74,3 +74,26 @@ def test_bucketed_allreduce_matches_serial_mean(tmp_path):
     p0, p1 = torch.load(tmp_path / "params0.pt"), torch.load(tmp_path / "params1.pt")
     for a, b in zip(p0, p1):
         assert torch.equal(a, b)  # replicas stay in lock-step after two optimizer steps
+
+
+@pytest.mark.timeout(300)
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` from a bare shell (no WORLD_SIZE) starts two fresh ranks itself and relays rank 0's
+    JSON line; --launch-check stops after the rendezvous so the test needs no GPU."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
+                       capture_output=True, text=True, env=env, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["ranks_seen"] == 2 and out["n_gpus"] == 2
+    # a rank that fails makes the parent exit non-zero
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check", "--dtype", "nope"],
+                       capture_output=True, text=True, env=env, timeout=280)
+    assert r.returncode != 0
