@@ -20,40 +20,11 @@
 #include "common.h"
 #include <type_traits>
 #include "dma.h"
+#include "conv_params.h"
 #include "profile.h"
 
 namespace {
 
-struct ConvParams {
-  const void* in;
-  const void* wt;
-  void* out;
-  const float* bias;
-  const float* pre_scale;
-  const float* pre_shift;
-  const float* post_scale;
-  const float* post_shift;
-  float* stats;  // [gridM][2][Cout] or null
-  int N, H, W, Cin, Cout, KH, KW, stride, pad, dil, Ho, Wo;
-  int M;
-  int act, stats_mode;  // stats_mode: 0 none, 1 after bias (pre-affine), 2 after activation
-  long out_image_stride;  // elements between consecutive images of the output (>= Ho*Wo*Cout)
-  int dbg;                // tuning ablation: 1 = no DMA inside the loop, 2 = no MFMA/ds_read (results invalid)
-  int in_dilate;          // >1: the input is read as if zero-dilated by this factor (dgrad of a strided conv)
-  int gridM, gridN;
-  int splits;       // > 1: split-K - grid.y splits each accumulate a slice of the K stages into `partial`
-  float* partial;   // [splits][M][Cout] fp32 (caller workspace)
-  long partial_bytes;
-  const void* add;  // optional tensor of the output's shape added in the epilogue (dense output only): the identity
-                    // branch's gradient riding on a residual block's first dgrad instead of a separate add kernel
-  // Parity classes of a strided conv's dgrad (sihl_conv2d_dgrad_add, LDS-DMA kernel only): the launch walks a KHxKW
-  // SUBSET of a w_kh x w_kw weight window - window tap (ky, kx) multiplies weight tap (w_ky0 + ky*w_kys, w_kx0 +
-  // kx*w_kxs) - and scatters output pixel (i, j) to (i*out_s + out_py, j*out_s + out_px) of an out_W-wide image.
-  int w_ntaps, w_kw, w_ky0, w_kys, w_kx0, w_kxs;  // defaults: KH*KW, KW, 0, 1, 0, 1
-  int out_s, out_py, out_px, out_W;                // defaults: 1, 0, 0, Wo
-  int add_stride;   // > 1: the addend is [N][add_H][add_W][Cout] and lands on output pixels (y, x) with y % add_stride
-  int add_H, add_W; // == 0 and x % add_stride == 0 only (input gradient of a strided 1x1 projection: zero elsewhere)
-};
 
 // element offset of output row m in the addend, or -1 where a strided addend has nothing to add
 __device__ __forceinline__ long add_offset(const ConvParams& p, int m) {
@@ -434,7 +405,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 // NBUF LDS stages: NBUF - 1 stages of DMA are in flight while one is multiplied.  Two suffice for the 256x256 tile
 // (a stage of MFMAs outlasts a DMA round trip); the narrow tiles of small / thin layers were bound by one DMA
 // latency per 64-deep stage and take 3-4.
-template <int N> __device__ __forceinline__ void wait_vm_keep() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <typename T, int BM, int BN, int WM, int WN, bool DIL, int NBUF, bool ADD = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(const ConvParams p) {
@@ -1013,8 +983,10 @@ int dispatch(const ConvParams& p, hipStream_t stream) {
       // window lose (r2 128>512: 63 -> 66, L3 3x3: 156 -> 182)
       if (g_tile_override == 0 && !(g_rules_off & 2) && p.M >= 256 * 256 && p.KH * p.KW == 1 && p.Cin <= 256 && p.Cout <= 256)
         return launch_n128<T>(p, stream);
-      if (g_tile_override == 256 || (g_tile_override == 0 && p.M >= 256 * 256))
+      if (g_tile_override == 256 || (g_tile_override == 0 && p.M >= 256 * 256)) {
+        if (sihl_p8_eligible(p)) return sihl_p8_launch(p, stream);
         return launch_dma<T, 256, 256, 4, 2>(p, stream);
+      }
     }
     if (g_tile_override == 64 || (g_tile_override == 0 && tiles128 * ((p.Cout + 255) / 256) <= 64))
       return launch_n64<T>(p, stream);
@@ -1053,6 +1025,9 @@ int sihl_conv2d_force_register_staging(int on) { g_force_reg = on != 0; return 0
 
 // Tuning ablation (results invalid when non-zero): 1 = skip the in-loop DMA, 2 = skip ds_read/MFMA.
 int sihl_conv2d_debug(int mode) { g_dbg = mode; return 0; }
+
+// Tuning / test hook: 0 = the two-stage 256x256 tile instead of the persistent 8-phase kernel (conv_p8.h).
+int sihl_conv2d_p8_enable(int on) { sihl_p8_set_enabled(on != 0); return 0; }
 
 // Tuning hook: LDS stages of the narrow-tile LDS-DMA kernels (0 = default, 2..4).
 int sihl_conv2d_nbuf_override(int n) { g_nbuf = n; return 0; }

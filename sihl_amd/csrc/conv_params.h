@@ -1,0 +1,39 @@
+// Launch parameters shared by the implicit-GEMM conv kernels (conv_igemm.hip, conv_p8.h).
+#pragma once
+#include "common.h"
+
+struct ConvParams {
+  const void* in;
+  const void* wt;
+  void* out;
+  const float* bias;
+  const float* pre_scale;
+  const float* pre_shift;
+  const float* post_scale;
+  const float* post_shift;
+  float* stats;  // [gridM][2][Cout] or null
+  int N, H, W, Cin, Cout, KH, KW, stride, pad, dil, Ho, Wo;
+  int M;
+  int act, stats_mode;  // stats_mode: 0 none, 1 after bias (pre-affine), 2 after activation
+  long out_image_stride;  // elements between consecutive images of the output (>= Ho*Wo*Cout)
+  int dbg;                // tuning ablation: 1 = no DMA inside the loop, 2 = no MFMA/ds_read (results invalid)
+  int in_dilate;          // >1: the input is read as if zero-dilated by this factor (dgrad of a strided conv)
+  int gridM, gridN;
+  int splits;       // > 1: split-K - grid.y splits each accumulate a slice of the K stages into `partial`
+  float* partial;   // [splits][M][Cout] fp32 (caller workspace)
+  long partial_bytes;
+  const void* add;  // optional tensor of the output's shape added in the epilogue (dense output only): the identity
+                    // branch's gradient riding on a residual block's first dgrad instead of a separate add kernel
+  // Parity classes of a strided conv's dgrad (sihl_conv2d_dgrad_add, LDS-DMA kernel only): the launch walks a KHxKW
+  // SUBSET of a w_kh x w_kw weight window - window tap (ky, kx) multiplies weight tap (w_ky0 + ky*w_kys, w_kx0 +
+  // kx*w_kxs) - and scatters output pixel (i, j) to (i*out_s + out_py, j*out_s + out_px) of an out_W-wide image.
+  int w_ntaps, w_kw, w_ky0, w_kys, w_kx0, w_kxs;  // defaults: KH*KW, KW, 0, 1, 0, 1
+  int out_s, out_py, out_px, out_W;                // defaults: 1, 0, 0, Wo
+  int add_stride;   // > 1: the addend is [N][add_H][add_W][Cout] and lands on output pixels (y, x) with y % add_stride
+  int add_H, add_W; // == 0 and x % add_stride == 0 only (input gradient of a strided 1x1 projection: zero elsewhere)
+};
+
+// conv_p8.hip: persistent 256x256 bf16 kernel
+bool sihl_p8_eligible(const ConvParams& p);
+int sihl_p8_launch(const ConvParams& p, hipStream_t stream);
+void sihl_p8_set_enabled(bool on);

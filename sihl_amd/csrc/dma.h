@@ -36,5 +36,7 @@ __device__ __forceinline__ void dma16(unsigned voff, unsigned lds_dst, v4i_t rsr
       : "memory");
 }
 
+// wait until at most N of this wave's newest vector-memory operations are still in flight (they retire in order)
+template <int N> __device__ __forceinline__ void wait_vm_keep() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 }  // namespace
