@@ -249,7 +249,8 @@ def main():
 
     lib = _C.lib()
     if args.wgrad_target:
-        lib.sihl_conv2d_wgrad_target(args.wgrad_target)
+        from sihl_amd import ops
+        ops.SIDE_WGRAD_TARGET = args.wgrad_target
     if os.environ.get("SIHL_NO_STRIDED_CLASSES"):  # A/B switch: zero-dilated read for the 3x3 stride-2 dgrads
         lib.sihl_conv2d_strided_classes_enable(0)
     for i in range(n_warm):

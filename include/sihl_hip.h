@@ -14,7 +14,8 @@
  *   - ownership: every buffer is caller-owned device memory (PyTorch's caching allocator in sihl_amd);
  *     kernels never allocate.  Scratch comes in through (ws, ws_bytes); the *_ws_bytes helpers size it.
  *   - streams: every launch goes to the hipStream_t argument, no implicit synchronisation, no global
- *     mutable state except the opt-in launch profiler; entries are re-entrant.
+ *     mutable state except the opt-in launch profiler and the test / tuning hooks (sihl_conv2d_*_override,
+ *     *_enable, *_force_*, sihl_conv2d_debug: never called by the product path); entries are re-entrant.
  *   - errors: 0 = ok, SIHL_EARG (-1) = bad argument / unsupported shape, SIHL_EWS (-2) = workspace too
  *     small, > 0 = hipError_t.  Nothing throws across the ABI.
  */
@@ -96,15 +97,15 @@ int sihl_conv2d_rules_off(int mask);   /* tuning hook: disable individual dispat
 /* Test hook: bf16 layers with >= 128 channels use an LDS-DMA 256x256-panel kernel; on != 0 forces the
  * register-staged 128x128 kernel (the fp32 / small-channel path) so both stay parity-tested. */
 int sihl_conv2d_wgrad_force_register_staging(int on);
-/* K-split target (workgroups) of the wgrad kernels: workgroups % 10000 for the LDS-DMA kernel (0 = 256, one per CU),
- * workgroups / 10000 for the register-staged / all-taps kernels (0 = default).  Process-wide; the workspace query
- * follows it.  The two-stream training step sets 128 / 128 while weight gradients run beside the dgrad chain. */
-int sihl_conv2d_wgrad_target(int workgroups);
+/* target: K-split aim (workgroups) of THIS call - target % 10000 for the LDS-DMA kernel (0 = 256, one per CU),
+ * target / 10000 for the register-staged / all-taps kernels (0 = default).  A per-call argument (no process-wide
+ * state): the workspace query takes the same value.  The two-stream training step passes 128 / 128 for the weight
+ * gradients that run beside the dgrad chain. */
 long sihl_conv2d_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                int dil, int dtype);
+                                int dil, int dtype, int target);
 int sihl_conv2d_wgrad(const void* in, const void* dout, float* dw, int N, int H, int W, int Cin, int Cout, int KH,
-                      int KW, int stride, int pad, int dil, int dtype, int accumulate, void* ws, long ws_bytes,
-                      hipStream_t stream);
+                      int KW, int stride, int pad, int dil, int dtype, int accumulate, int target, void* ws,
+                      long ws_bytes, hipStream_t stream);
 
 /* [Cout][KH][KW][Cin] -> [Cin][KH][KW][Cout], spatially flipped when flip != 0: the weights with which
  * sihl_conv2d_fwd computes the INPUT gradient of a stride-1 conv (pad' = dil*(K-1) - pad) or of a Linear. */

@@ -35,9 +35,8 @@ SIGNATURES = {
     "sihl_conv2d_splitk_enable": (I, [I]),
     "sihl_conv2d_rules_off": (I, [I]),
     "sihl_conv2d_wgrad_force_register_staging": (I, [I]),
-    "sihl_conv2d_wgrad_target": (I, [I]),
-    "sihl_conv2d_wgrad_ws_bytes": (L, [I, I, I, I, I, I, I, I, I, I, I]),
-    "sihl_conv2d_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, L, P]),
+    "sihl_conv2d_wgrad_ws_bytes": (L, [I, I, I, I, I, I, I, I, I, I, I, I]),
+    "sihl_conv2d_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P, L, P]),
     "sihl_weight_flip_transpose": (I, [P, P, I, I, I, I, I, I, I, P]),
     "sihl_weight_prepare": (I, [P, I, L, L, P]),
     "sihl_bn_finalize": (I, [P, I, I, L, P, P, F, F, P, P, P, P, P, P, P]),

@@ -591,18 +591,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(const Conv
   __syncthreads();
 
   int buf = 0, nbuf_next = NBUF - 1;  // LDS stage being multiplied / being filled
-  for (int s = 0; s < ((p.dbg & 64) ? 0 : nstages); ++s) {  // dbg 64: tuning ablation, prologue + epilogue only
-    const bool more = (s + NBUF - 1 < nstages) && !(p.dbg & 1);
+  for (int s = 0; s < ((SIHL_DBG(p) & 64) ? 0 : nstages); ++s) {  // dbg 64: tuning ablation, prologue + epilogue only
+    const bool more = (s + NBUF - 1 < nstages) && !(SIHL_DBG(p) & 1);
     if (more) stage_setup(s + NBUF - 1, nbuf_next);
     const char* As = smem + buf * STAGE + wm * WTM * KCB;
     const char* Bs = smem + buf * STAGE + A_BYTES + wn * WTN * KCB;
-    // DMA issue schedule for the next stage (p.dbg bits 2-3 select it while tuning):
+    // DMA issue schedule for the next stage (SIHL_DBG(p) bits 2-3 select it while tuning):
     //   0: NA/NBL slots spread over the k-steps   1: everything before the first k-step
     //   2: staggered - waves of the first half issue before k-step 0, the others after k-step 1
     //   3: front-loaded - slots spread over the first half of the k-steps
-    const int sched = (p.dbg & 16) ? ((p.dbg >> 2) & 3) : ((BM >= 256 && NBUF == 2) ? 3 : 1);
+    const int sched = (SIHL_DBG(p) & 16) ? ((SIHL_DBG(p) >> 2) & 3) : ((BM >= 256 && NBUF == 2) ? 3 : 1);
     const bool early = sched == 1 || (sched == 2 && wave < WM * WN / 2);
-    if (!(p.dbg & 2)) {
+    if (!(SIHL_DBG(p) & 2)) {
       uint4 fa[2][MT], fb[2][NT];
 #pragma unroll
       for (int i = 0; i < MT; ++i) fa[0][i] = *(const uint4*)(As + i * 32 * KCB + koff[0]);
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(const Conv
     nbuf_next = nbuf_next + 1 == NBUF ? 0 : nbuf_next + 1;
   }
   }  // NBUF > 1
-  if (p.dbg & 32) return;  // tuning ablation: no epilogue
+  if (SIHL_DBG(p) & 32) return;  // tuning ablation: no epilogue
   if (p.splits > 1) {  // raw fp32 partial tile; conv_splitk_epilogue_kernel sums the splits and finishes
     float* part = p.partial + (long)blockIdx.y * p.M * p.Cout;
     const int half = lane >> 5;
@@ -1090,7 +1090,7 @@ int sihl_conv2d_fwd_ws(const void* in, const void* wt, const float* bias, void* 
   p.act = act; p.stats_mode = stats_mode;
   p.gridM = p.gridN = 0;
   p.in_dilate = 1;
-  p.dbg = g_dbg;
+  p.dbg = g_dbg;  // read by the kernels in SIHL_TUNING builds only
   p.out_image_stride = out_image_stride > 0 ? out_image_stride : (long)p.Ho * p.Wo * Cout;
   if (p.out_image_stride < (long)p.Ho * p.Wo * Cout) return SIHL_EARG;
   if (p.out_image_stride % (dtype == SIHL_BF16 ? 8 : 4)) return SIHL_EARG;

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(P8_THREADS) void conv_p8_kernel(const ConvParams p)
     n_tapbit = 1u << is_tap;
   };
   // half-tile hq of the K-tile the issuer stands on: 0 = A0, 1 = B0, 2 = A1, 3 = B1 (LDS order inside a K-tile buffer)
-  const int dbg = p.dbg;  // tuning ablations (results invalid): 1 no DMA in the loop, 2 no MFMA, 8 no stagger,
+  const int dbg = SIHL_DBG(p);  // tuning ablations (results invalid): 1 no DMA in the loop, 2 no MFMA, 8 no stagger,
                           // 16 no epilogue; 32 (a valid schedule): one barrier per phase, no stagger
   bool in_loop = false;
   auto issue = [&](int hq) {

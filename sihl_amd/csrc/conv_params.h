@@ -2,6 +2,14 @@
 #pragma once
 #include "common.h"
 
+// Tuning ablations (sihl_conv2d_debug) are compiled into the kernels only in SIHL_TUNING builds (make TUNING=1): the
+// shipped hot loops carry no debug branches.
+#ifdef SIHL_TUNING
+#define SIHL_DBG(p) ((p).dbg)
+#else
+#define SIHL_DBG(p) 0
+#endif
+
 struct ConvParams {
   const void* in;
   const void* wt;

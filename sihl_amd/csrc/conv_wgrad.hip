@@ -515,8 +515,6 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 }
 
 bool g_wgrad_force_reg = false;
-int g_wgrad_target = 0;  // tuning hook: workgroups the LDS-DMA kernel's K-split aims for (0 = default)
-int g_wgrad_target_reg = 0;  // same for the register-staged and all-taps kernels (0 = default)
 
 bool use_dma(int Cin, int Cout, long in_bytes, long dy_bytes, int dtype) {
   // exactly 128x128 channels would leave three quarters of the 256x256 panel empty (228 us against 130 us for the
@@ -551,7 +549,10 @@ int launch_alltaps(WgradParams p, hipStream_t stream) {
 // Tiling / split decision shared by the workspace query and the launcher.
 struct WgradPlan { int mode /*0 reg, 1 dma, 2 all-taps*/, tiles_co, tiles_ci, splits, kp; };
 int choose_splits(long M, int tiles, int kp, int target, long n_weights);
-WgradPlan plan_wgrad(long M, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dtype) {
+// target: K-split aim in workgroups, per call: target % 10000 for the LDS-DMA kernel (0 = 256, one per CU),
+// target / 10000 for the register-staged / all-taps kernels (0 = default)
+WgradPlan plan_wgrad(long M, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dtype, int target) {
+  const int g_wgrad_target = target > 0 ? target % 10000 : 0, g_wgrad_target_reg = target > 0 ? target / 10000 : 0;
   const int vs = dtype == SIHL_BF16 ? 2 : 4;
   WgradPlan pl;
   const long n_weights = (long)Cout * KH * KW * Cin;
@@ -635,24 +636,23 @@ extern "C" {
 
 // Test hook: 1 = always use the register-staged 128x128 kernel (the fp32 / small-channel path).
 int sihl_conv2d_wgrad_force_register_staging(int on) { g_wgrad_force_reg = on != 0; return 0; }
-// Tuning hook: workgroups the LDS-DMA wgrad kernel's K-split aims for (0 = default, one per CU).  Fewer, longer
-// workgroups write fewer fp32 partial slabs and leave CUs to the kernels of the other stream.
-int sihl_conv2d_wgrad_target(int workgroups) { g_wgrad_target = workgroups % 10000; g_wgrad_target_reg = workgroups / 10000; return 0; }
 
 // Workspace bytes sihl_conv2d_wgrad needs for this problem.
 long sihl_conv2d_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                int dil, int dtype) {
+                                int dil, int dtype, int target) {
   const int Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
   const int Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   const long M = (long)N * Ho * Wo;
-  const int splits = plan_wgrad(M, N, H, W, Cin, Cout, KH, KW, dtype).splits;
+  const int splits = plan_wgrad(M, N, H, W, Cin, Cout, KH, KW, dtype, target).splits;
   return (long)splits * Cout * KH * KW * Cin * (long)sizeof(float);
 }
 
-// dw: fp32 [Cout][KH][KW][Cin]; accumulate != 0 adds into dw instead of overwriting.
+// dw: fp32 [Cout][KH][KW][Cin]; accumulate != 0 adds into dw instead of overwriting.  target: K-split aim of THIS call
+// (0 = default; fewer, longer workgroups write fewer fp32 partial slabs and leave CUs to kernels of another stream) -
+// the same value must be given to sihl_conv2d_wgrad_ws_bytes.
 int sihl_conv2d_wgrad(const void* in, const void* dout, float* dw, int N, int H, int W, int Cin, int Cout, int KH,
-                      int KW, int stride, int pad, int dil, int dtype, int accumulate, void* ws, long ws_bytes,
-                      hipStream_t stream) {
+                      int KW, int stride, int pad, int dil, int dtype, int accumulate, int target, void* ws,
+                      long ws_bytes, hipStream_t stream) {
   if (!in || !dout || !dw || !ws || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SIHL_EARG;
   const int vec = dtype == SIHL_BF16 ? 8 : 4;
   if (Cin % vec || Cout % vec) return SIHL_EARG;
@@ -665,7 +665,7 @@ int sihl_conv2d_wgrad(const void* in, const void* dout, float* dw, int N, int H,
   const long M = (long)N * p.Ho * p.Wo;
   if (p.Ho <= 0 || p.Wo <= 0 || M > (1L << 30)) return SIHL_EARG;
   p.M = (int)M;
-  const WgradPlan pl = plan_wgrad(M, N, H, W, Cin, Cout, KH, KW, dtype);
+  const WgradPlan pl = plan_wgrad(M, N, H, W, Cin, Cout, KH, KW, dtype, target);
   const bool dma = pl.mode == 1;
   const int kp = pl.kp;
   p.tiles_co = pl.tiles_co; p.tiles_ci = pl.tiles_ci; p.splits = pl.splits;

@@ -102,7 +102,12 @@ class _Side:
 _SIDE: Optional[_Side] = None
 _SIDE_STREAMS = {}
 WGRAD_SIDE_MAX_PIXELS = {"off": 0, "small": 32 * 32 * 32, "all": 1 << 62}
-SIDE_WGRAD_TARGET = 128 + 10000 * 128  # sihl_conv2d_wgrad_target: LDS-DMA kernel + 10000 x register-staged kernels
+# K-split aim of weight gradients launched beside the dgrad chain (the `target` argument of sihl_conv2d_wgrad: LDS-DMA
+# kernel + 10000 x register-staged kernels): they should not claim the whole chip - 128 workgroups instead of one per
+# CU write half the fp32 partial slabs and leave CUs to the main stream (flagship step, same box: 35.4-35.8 ->
+# 34.4-34.7 ms; 64-96 workgroups about the same, 32: 40.2 ms)
+SIDE_WGRAD_TARGET = 128 + 10000 * 128
+WGRAD_TARGET = 0  # K-split aim of weight gradients on the main stream (0 = library default, one workgroup per CU)
 
 
 def side_stream(device, priority: int = 0):
@@ -137,10 +142,6 @@ class wgrad_side_stream:
         if self.mode != "off" and torch.cuda.is_available():
             dev = torch.cuda.current_device() if self.device is None else torch.device(self.device).index
             _SIDE = _Side(side_stream(dev, self.priority), self.mode)
-            # beside the dgrad chain a weight gradient should not claim the whole chip: K-splits aimed at 128
-            # workgroups instead of one per CU write half the fp32 partial slabs and leave CUs to the main stream
-            # (flagship step, same box: 35.4-35.8 -> 34.4-34.7 ms; 64-96 workgroups about the same, 32: 40.2 ms)
-            _C.lib().sihl_conv2d_wgrad_target(SIDE_WGRAD_TARGET)
         else:
             _SIDE = None
         return self
@@ -148,8 +149,6 @@ class wgrad_side_stream:
     def __exit__(self, *exc):
         global _SIDE
         join_side_stream()
-        if _SIDE is not None:
-            _C.lib().sihl_conv2d_wgrad_target(0)
         _SIDE = self._outer
         return False
 
@@ -159,11 +158,22 @@ def side_stream_in_use():
     return _SIDE.stream if _SIDE is not None and _SIDE.dirty else None
 
 
+_RETIRED = []  # (event recorded on the side stream after its last kernel, operands those kernels read)
+
+
 def join_side_stream() -> None:
-    """The current stream waits for every weight gradient queued on the side stream so far."""
+    """The current stream waits for every weight gradient queued on the side stream so far.  The operands the side
+    stream read are released only once an event recorded behind its last kernel has COMPLETED (not merely been
+    waited for by the main stream): whichever stream or pool their blocks go to next, no queued reader is left."""
+    for k in range(len(_RETIRED) - 1, -1, -1):
+        if _RETIRED[k][0].query():
+            del _RETIRED[k]
     if _SIDE is not None and _SIDE.dirty:
-        torch.cuda.current_stream().wait_stream(_SIDE.stream)
-        _SIDE.holds.clear()
+        ev = torch.cuda.Event()
+        ev.record(_SIDE.stream)
+        torch.cuda.current_stream().wait_event(ev)
+        _RETIRED.append((ev, _SIDE.holds))
+        _SIDE.holds = []
         _SIDE.dirty = False
 
 
@@ -311,21 +321,24 @@ def conv2d_wgrad_raw(x: Tensor, dout: Tensor, KH: int, KW: int, stride: int, pad
     N, H, W, Cin = x.shape
     Cout = dout.shape[-1]
     lib = _C.lib()
-    nbytes = lib.sihl_conv2d_wgrad_ws_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x))
-    dw = torch.empty((Cout, KH, KW, Cin), dtype=torch.float32, device=x.device)  # main-stream allocation either way
+    # dw is a main-stream allocation either way: it is consumed on the main stream (optimizer, clipping, all-reduce) after
+    # the join, and its block goes back to the main stream's pool
+    dw = torch.empty((Cout, KH, KW, Cin), dtype=torch.float32, device=x.device)
     side = _SIDE
     if side is not None and dout.numel() // Cout <= WGRAD_SIDE_MAX_PIXELS[side.mode]:
+        nbytes = lib.sihl_conv2d_wgrad_ws_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x), SIDE_WGRAD_TARGET)
         side.stream.wait_stream(torch.cuda.current_stream())  # x and dout are complete on the main stream
         with torch.cuda.stream(side.stream):
             ws = workspace(nbytes, x.device)  # the side stream's own scratch buffer (keyed by stream)
             rc = lib.sihl_conv2d_wgrad(_p(x), _p(dout), _p(dw), N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x),
-                                       0, _p(ws), ws.numel(), _stream())
-        side.holds.append((x, dout))
+                                       0, SIDE_WGRAD_TARGET, _p(ws), ws.numel(), _stream())
+        side.holds.append((x, dout, dw))
         side.dirty = True
     else:
+        nbytes = lib.sihl_conv2d_wgrad_ws_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x), WGRAD_TARGET)
         ws = workspace(nbytes, x.device)
         rc = lib.sihl_conv2d_wgrad(_p(x), _p(dout), _p(dw), N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x), 0,
-                                   _p(ws), ws.numel(), _stream())
+                                   WGRAD_TARGET, _p(ws), ws.numel(), _stream())
     check(rc, "sihl_conv2d_wgrad")
     return dw
 

@@ -201,10 +201,25 @@ class Trainer:
         on_gpu = all(p.is_cuda for p in model.parameters())
         self.use_graph = bool(graph) and world == 1 and on_gpu
         if self.use_graph:
-            # graph mode is single-stream THROUGHOUT, warm-up steps included: two-stream eager warm-up steps followed
-            # by a capture ended in a GPU memory access fault on a later step in every process but the first on a box
-            # (three of three; never with single-stream warm-up, never in eager mode) - cause not isolated this round
-            self.wgrad_stream = os.environ.get("SIHL_GRAPH_WARMUP_STREAM", "off")  # env: debugging only
+            # a graph Trainer is single-stream THROUGHOUT, warm-up steps included (a capture that
+            # followed two-stream eager steps faulted on a later replay; the captured step never uses a second stream)
+            self.wgrad_stream = opt_kw.pop("_graph_warmup_stream", "off")  # private: tools/graph_phase_probe.py only
+        else:
+            opt_kw.pop("_graph_warmup_stream", None)
+        if self.wgrad_stream != "off" and on_gpu:
+            # weight gradients written by the side stream are handed to autograd while that stream may still be
+            # writing them; that is safe only while AccumulateGrad takes the tensor as it is (no kernel): fp32 parameters,
+            # 4-D weights stored channels_last (the kernels' [O][KH][KW][I] layout), one use per step.  Anything else
+            # keeps the weight gradients on the main stream.
+            for name, p in model.named_parameters():
+                bad = p.dtype != torch.float32 or (p.dim() == 4 and p.shape[2] * p.shape[3] > 1 and
+                                                   not p.is_contiguous(memory_format=torch.channels_last))
+                if bad:
+                    import warnings
+                    warnings.warn(f"wgrad_stream={self.wgrad_stream!r} needs fp32 parameters with channels_last conv "
+                                  f"weights ({name} is not): weight gradients stay on the main stream")
+                    self.wgrad_stream = "off"
+                    break
         if self.use_graph and optimizer is None:
             opt_kw.setdefault("capturable", True)  # optimizer step counters live on the device
         self.optimizer = optimizer or configure_optimizer(model, **opt_kw)
@@ -280,7 +295,6 @@ class Trainer:
         head, ~1 ms of small launches at bs 32) compute it on the side stream while the backbone and the neck run.
         Returns the stream to wait for before the heads' training_step, or None."""
         if (self.wgrad_stream == "off" or not images.is_cuda or torch.cuda.is_current_stream_capturing()
-                or os.environ.get("SIHL_NO_PREMATCH")
                 or not any(hasattr(h, "prematch") for h in self.model.heads)):
             return None
         from sihl_amd import ops

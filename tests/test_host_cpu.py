@@ -54,7 +54,9 @@ def test_argument_errors_without_gpu():
     assert lib.sihl_conv2d_fwd(None, None, None, None, 1, 1, 1, 8, 8, 1, 1, 1, 0, 1, 0, 0, None, None, None, None,
                                0, None, 0, 0, None) == -1
     assert lib.sihl_topk_rows(None, 1, 10, 5, 1, None, None, 0, None) == -1
-    assert lib.sihl_conv2d_wgrad_ws_bytes(32, 64, 64, 256, 256, 3, 3, 1, 1, 1, 1) > 0
+    full = lib.sihl_conv2d_wgrad_ws_bytes(32, 64, 64, 256, 256, 3, 3, 1, 1, 1, 1, 0)
+    half = lib.sihl_conv2d_wgrad_ws_bytes(32, 64, 64, 256, 256, 3, 3, 1, 1, 1, 1, 128)
+    assert full > half > 0  # the K-split aim is a per-call argument: fewer workgroups, fewer fp32 partial slabs
 
 
 def test_no_cpu_fallback():
