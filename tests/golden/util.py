@@ -76,3 +76,37 @@ def quantized_copy(data):
         if is_in or is_w:
             out[k] = torch.from_numpy(v.copy()).bfloat16().float().numpy()
     return out
+
+
+class TinyBackbone(torch.nn.Module):
+    """Plain-torch stand-in backbone honouring the reference's level contract (torchvision_backbone.py:161-186): returns
+    [input, level 1 .. level 5], level l at 1 / 2^l of the input, ``out_channels`` lists their channels.  Used by the
+    caller fixture (the real backbones are third-party and absent offline); conv -> BN -> ReLU stages so that the
+    optimizer grouping sees backbone weights, biases-free convs and norm parameters."""
+
+    def __init__(self, channels=(3, 8, 16, 24, 32, 48)):
+        super().__init__()
+        nn = torch.nn
+        self.out_channels = list(channels)
+        self.stages = nn.ModuleList(
+            nn.Sequential(nn.Conv2d(cin, cout, 3, stride=2, padding=1, bias=(i == 0)), nn.BatchNorm2d(cout), nn.ReLU())
+            for i, (cin, cout) in enumerate(zip(channels[:-1], channels[1:])))
+        self.dummy_input = torch.zeros(1, 3, 64, 64)
+
+    def forward(self, x):
+        out = [x]
+        for s in self.stages:
+            out.append(s(out[-1]))
+        return out
+
+
+CALLER = dict(neck_channels=32, bottom=3, top=5, num_classes=6, image=64, batch=2,
+              opt=dict(lr=1e-3, weight_decay=1e-2, backbone_lr_factor=0.1), warmup=3, t_max=10, sched_steps=8)
+
+
+def caller_batch():
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(CALLER["batch"], 3, CALLER["image"], CALLER["image"], generator=g)
+    boxes = [torch.tensor([[5.2, 7.9, 40.3, 33.1], [22.4, 30.6, 58.7, 61.2]]), torch.tensor([[10.5, 12.25, 30.75, 50.5]])]
+    classes = [torch.tensor([1, 4]), torch.tensor([2])]
+    return x, {"classes": classes, "boxes": boxes}
