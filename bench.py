@@ -75,8 +75,11 @@ def usable_cores():
     return cores
 
 
-def cpu_baseline(sample_batch, size, iters=4):
-    """The oracle (CPU port of the reference path) on a bounded sample: same model, same step, fp32."""
+def cpu_baseline(sample_batch, size, iters=5, warm=2):
+    """The oracle (CPU port of the reference path) on a bounded sample: same model, same step, fp32; median of `iters`
+    steps after `warm` warm-ups.  The sample is a smaller BATCH of the same 512x512 workload (images are
+    independent, so images/s does not depend on it beyond cache effects): bs 32 costs ~8 s per step on 16 cores, 7 steps
+    of it would double the bench's run time."""
     import types
 
     import oracle
@@ -89,14 +92,58 @@ def cpu_baseline(sample_batch, size, iters=4):
     model = build_model(ns, "cpu")
     trainer = Trainer(model, lr=1e-4, weight_decay=1e-4, backbone_lr_factor=0.1)
     images, targets = synthetic_batch(sample_batch, size, "cpu", seed=0)
-    trainer.step(images, targets)  # warm-up
-    t0 = time.perf_counter()
-    for _ in range(iters):
+    for _ in range(warm):
         trainer.step(images, targets)
-    dt = (time.perf_counter() - t0) / iters
+    times = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        trainer.step(images, targets)
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]
     return {"value": sample_batch / dt, "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"oracle (CPU fp32 restatement) fwd+bwd+step, bs={sample_batch} of the same {size}x{size} "
-                      f"workload, mean of {iters} steps after 1 warm-up ({dt:.2f} s/step)"}
+                      f"workload, median of {iters} steps after {warm} warm-ups ({dt:.2f} s/step)"}
+
+
+def source_stamp():
+    """sha256 over the kernel sources: profiles/*pmc*.json carry it, so a traffic figure measured on other code is
+    recognisably stale."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "sihl_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "sihl_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_peaks(device):
+    """On-box yardsticks: streaming copy (read + write bytes per second) and a vendor bf16 GEMM
+    (torch.matmul = hipBLASLt / rocBLAS), both on random data, HIP events, best of 3 rounds."""
+    n = 1 << 28  # 512 MiB of bf16 per buffer: past the 256 MiB Infinity Cache
+    src = torch.randn(n, device=device, dtype=torch.bfloat16)
+    dst = torch.empty_like(src)
+    a = torch.randn(8192, 8192, device=device, dtype=torch.bfloat16)
+    bmat = torch.randn(8192, 8192, device=device, dtype=torch.bfloat16)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def best(fn, reps):
+        fn()
+        t = 1e9
+        for _ in range(3):
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            t = min(t, e0.elapsed_time(e1) / reps)
+        return t * 1e-3
+
+    t_copy = best(lambda: dst.copy_(src), 10)
+    t_gemm = best(lambda: torch.matmul(a, bmat), 10)
+    return {"copy_GBps": 2 * n * 2 / t_copy / 1e9, "gemm_bf16_TFLOPs": 2 * 8192 ** 3 / t_gemm / 1e12,
+            "what": "torch copy_ of 512 MiB (bytes read + written), torch.matmul 8192^3 bf16 (vendor GEMM), random data"}
 
 
 def north_star_forward(model, device, dtype, batch, size, iters=20):
@@ -160,7 +207,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=4)
+    ap.add_argument("--cpu-sample", type=int, default=4, help="batch of the CPU-baseline sample (see cpu_baseline)")
     ap.add_argument("--backbone", default="native", choices=["torch", "native"],
                     help="native (default) = ResNet50 residual stages on the sihl HIP kernels; torch = trunk on "
                          "PyTorch-ROCm/MIOpen")
@@ -181,6 +228,13 @@ def main():
     ap.add_argument("--rehearse-dp", action="store_true",
                     help="N=1 only: run the multi-GPU code path (process group of one rank, gradient buckets, hooks, "
                          "all-reduce calls on the collective's stream) on a single GPU")
+    ap.add_argument("--graph-warmup-stream", default="off", choices=["off", "small", "all"],
+                    help="debugging only, with --graph: stream mode of the eager warm-up steps before the capture (the "
+                         "round-1 fault needed 'all'; a graph Trainer otherwise never uses a second stream)")
+    ap.add_argument("--extra-stream", action="store_true",
+                    help="debugging: create a second HIP stream and run one trivial kernel on it before the warm-up")
+    ap.add_argument("--sync-warmup", action="store_true", help="debugging: synchronize after every warm-up step")
+    ap.add_argument("--sync-steps", action="store_true", help="debugging: synchronize after every timed step")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only (no GPU work): every rank joins the process group, rank 0 prints the number "
                          "of ranks seen - the CPU test of the self-launcher")
@@ -234,7 +288,8 @@ def main():
     use_graph = world == 1 and args.graph and not args.no_graph and not args.rehearse_dp
     trainer = Trainer(model, lr=1e-4, weight_decay=1e-4, backbone_lr_factor=0.1, grad_clip_norm=0.1,
                       autocast_dtype=amp, graph=use_graph, wgrad_stream=args.wgrad_stream,
-                      force_buckets=args.rehearse_dp)
+                      force_buckets=args.rehearse_dp,
+                      **({"_graph_warmup_stream": args.graph_warmup_stream} if use_graph else {}))
     images, targets = synthetic_batch(args.batch, args.size, device, seed=rank)
     # graph mode needs its eager warm-up steps + the capture before the timed region
     n_warm = max(args.warmup, Trainer.GRAPH_WARMUP + 1) if use_graph else args.warmup
@@ -253,14 +308,23 @@ def main():
         ops.SIDE_WGRAD_TARGET = args.wgrad_target
     if os.environ.get("SIHL_NO_STRIDED_CLASSES"):  # A/B switch: zero-dilated read for the 3x3 stride-2 dgrads
         lib.sihl_conv2d_strided_classes_enable(0)
+    if args.extra_stream:
+        extra = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(extra):
+            _dummy = torch.zeros(1024, device=device).add_(1)
+        torch.cuda.synchronize()
     for i in range(n_warm):
         trainer.step(images, targets)
+        if args.sync_warmup:
+            torch.cuda.synchronize()
         trace(f"warm-up step {i} issued")
     sync()
     trace("warm-up done")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = trainer.step(images, targets)
+        if args.sync_steps:
+            torch.cuda.synchronize()
     sync()
     dt = time.perf_counter() - t0
     trace("timed steps done")
@@ -278,9 +342,41 @@ def main():
     lib.sihl_profile_enable(0)
 
     fwd = None
+    sub = None
+    peaks = None
     if world == 1 and rank == 0 and not args.rehearse_dp:
         fwd = north_star_forward(model, device, amp or torch.float32, args.batch, args.size)
         trace("north-star forward probe done")
+        # sub-metrics of the same step: forward only, and forward + backward without clip / optimizer
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        model.train()
+        trainer.wgrad_stream = args.wgrad_stream
+        n_sub = 5
+
+        def timed(fn):
+            fn()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(n_sub):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n_sub
+
+        def fwd_only():
+            with torch.no_grad():
+                trainer.forward_loss(images, targets)
+
+        def fwd_bwd():
+            trainer.optimizer.zero_grad(set_to_none=True)
+            loss_, _ = trainer.forward_loss(images, targets)
+            trainer._backward(loss_)
+
+        sub = {"fwd_only_ms": timed(fwd_only), "fwd_bwd_no_opt_ms": timed(fwd_bwd),
+               "what": "training-mode forward + loss under no_grad; forward + backward without clip / AdamW / weight "
+                       f"preparation; eager, mean of {n_sub} after 1 warm-up"}
+        peaks = measured_peaks(device)
+        trace("sub-metrics and yardsticks done")
 
     t = torch.tensor([dt], device=device, dtype=torch.float64)
     seen = torch.ones(1, device=device, dtype=torch.float64)
@@ -314,19 +410,25 @@ def main():
     # HBM traffic of the conv kernel per launch: PMC counters need their own rocprofv3 passes (FETCH_SIZE, WRITE_SIZE;
     # profiles/pmc_summarize.py applies the gfx950 correction), so the figure comes from the committed summary of
     # those passes over this same command, not from this run
-    traffic = None
+    traffic, traffic_note = None, "no PMC summary for this source tree (profiles/r02_pmc_bench.json)"
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_s2_pmc_bench.json")))["kernels"]["conv_igemm_dma_kernel"]
-        if args.dtype == "bf16" and args.batch == 32 and args.size == 512:
+        pmc_all = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_bench.json")))
+        pmc = pmc_all["kernels"]["conv_igemm_dma_kernel"]
+        if pmc_all.get("source_stamp") != source_stamp():
+            traffic_note = (f"profiles/r02_pmc_bench.json was measured on other kernel sources (stamp "
+                            f"{pmc_all.get('source_stamp')} != {source_stamp()}): stale, not reported")
+        elif args.dtype == "bf16" and args.batch == 32 and args.size == 512:
             traffic = pmc["traffic_MB_per_launch"] * 1e6
+            traffic_note = ("HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes over this "
+                            "command, profiles/r02_pmc_bench.json, same source stamp); algorithmic bytes per launch: "
+                            "avg_algorithmic_mb_per_launch")
     except (OSError, KeyError, ValueError):
         pass
     if n.value:
         achieved = fl.value / (ms.value * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (NHWC implicit-GEMM conv: fwd / dgrad / linear)",
                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                    "traffic_note": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_s2_pmc_bench.json); "
-                                    "algorithmic bytes per launch: avg_algorithmic_mb_per_launch",
+                    "traffic_note": traffic_note,
                     "avg_algorithmic_mb_per_launch": by.value / n.value / 1e6,
                     "frac_of_per_launch_roofline": per_launch_roofline(0),  # each launch against min(MFMA, HBM) bound
                     "launches_per_step": n.value / profiled_steps, "avg_launch_us": ms.value * 1e3 / n.value,
@@ -359,6 +461,16 @@ def main():
         }
         if fwd is not None:
             out["north_star_forward"] = fwd
+        if sub is not None:
+            out["sub_metrics"] = sub
+        if peaks is not None:
+            out["measured_peaks"] = peaks
+            if roofline is not None:
+                roofline["frac_of_measured_gemm"] = roofline["achieved"] / peaks["gemm_bf16_TFLOPs"]
+            if fwd is not None:
+                fwd["frac_of_measured_gemm"] = fwd["achieved_tflops"] / peaks["gemm_bf16_TFLOPs"]
+                fwd["frac_of_measured_copy"] = fwd["algorithmic_hbm_gbps"] / peaks["copy_GBps"]
+        out["source_stamp"] = source_stamp()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.size)
         print(json.dumps(out), flush=True)

@@ -40,4 +40,4 @@ from oracle.heads import (  # noqa: F401
     complete_box_iou,
     complete_box_iou_loss,
 )
-from oracle.model import SihlModel, ResNetBackbone  # noqa: F401
+from oracle.model import SihlModel, ResNetBackbone, TimmBackbone  # noqa: F401

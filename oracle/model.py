@@ -144,3 +144,89 @@ class ResNetBackbone(nn.Module):
         for ds in self.downscalers:
             outs.append(ds(outs[-1]))
         return outs
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# TimmBackbone level contract (reference src/sihl/timm_backbone.py:95-187) around a ConvNeXt-shaped trunk restated from
+# the published architecture (timm 1.0.15 is not in the image: the trunk is "parity unpinned", the contract - fake
+# level 1, out_channels, nearest resize to the level size, extra downscalers - follows the reference's own lines).
+_CONVNEXTS = {"convnext_tiny": ((3, 3, 9, 3), (96, 192, 384, 768)), "convnext_small": ((3, 3, 27, 3), (96, 192, 384, 768)),
+              "convnext_base": ((3, 3, 27, 3), (128, 256, 512, 1024))}
+
+
+class _LN2d(nn.LayerNorm):
+    def forward(self, x):
+        return F.layer_norm(x.permute(0, 2, 3, 1), self.normalized_shape, self.weight, self.bias, self.eps).permute(0, 3, 1, 2)
+
+
+class _CNBlock(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.conv_dw = nn.Conv2d(dim, dim, 7, padding=3, groups=dim)
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+        self.fc1, self.act, self.fc2 = nn.Linear(dim, 4 * dim), nn.GELU(), nn.Linear(4 * dim, dim)
+        self.gamma = nn.Parameter(1e-6 * torch.ones(dim))
+
+    def forward(self, x):
+        y = self.conv_dw(x).permute(0, 2, 3, 1)
+        return x + (self.fc2(self.act(self.fc1(self.norm(y)))) * self.gamma).permute(0, 3, 1, 2)
+
+
+class _CNTrunk(nn.Module):
+    reductions = (4, 8, 16, 32)
+
+    def __init__(self, depths, dims, input_channels=3):
+        super().__init__()
+        self.stem = nn.Sequential(nn.Conv2d(input_channels, dims[0], 4, stride=4), _LN2d(dims[0], eps=1e-6))
+        self.stages = nn.ModuleList(
+            nn.Sequential(nn.Identity() if i == 0 else nn.Sequential(_LN2d(dims[i - 1], eps=1e-6),
+                                                                     nn.Conv2d(dims[i - 1], c, 2, stride=2)),
+                          *[_CNBlock(c) for _ in range(d)]) for i, (d, c) in enumerate(zip(depths, dims)))
+
+    def forward(self, x):
+        x = self.stem(x)
+        outs = []
+        for s in self.stages:
+            x = s(x)
+            outs.append(x)
+        return outs
+
+
+class TimmBackbone(nn.Module):
+    def __init__(self, name="convnext_base", pretrained=False, input_channels=3, top_level=5, frozen_levels=0,
+                 freeze_batchnorms=False, depths=None):
+        super().__init__()
+        if name not in _CONVNEXTS:
+            raise ValueError(f"Architecture {name} is not supported. Select from {tuple(_CONVNEXTS)}")
+        if pretrained:
+            raise RuntimeError("pretrained weights need network access; unavailable offline")
+        self.name, self.top_level = name, top_level
+        d, dims = _CONVNEXTS[name]
+        self.model = _CNTrunk(depths or d, dims, input_channels)
+        self.normalize = nn.Identity()
+        self.fake_level1 = 2 not in self.model.reductions  # timm_backbone.py:143-152
+        self.dummy_input = torch.zeros(1, input_channels, 2 ** (top_level + 1), 2 ** (top_level + 1))
+        with torch.no_grad():
+            self.out_channels = [input_channels] + [t.shape[1] for t in self._features(self.dummy_input)]
+        c = self.out_channels[-1]
+        extra = range(top_level - 5)
+        self.out_channels += [c for _ in extra]
+        self.downscalers = nn.ModuleList([AntialiasedDownscaler(c, c) for _ in extra])
+
+    def _features(self, x):
+        feats = self.model(x)
+        if self.fake_level1:
+            feats = [F.interpolate(x, size=(x.shape[2] // 2, x.shape[3] // 2))] + feats
+        return feats
+
+    def forward(self, input):
+        assert input.shape[2] % 2 ** self.top_level == 0 and input.shape[3] % 2 ** self.top_level == 0
+        x = self.normalize(input)
+        H, W = x.shape[2:]
+        outs = [input]
+        for lvl, t in zip(range(1, self.top_level + 1), self._features(x)):
+            size = (H // 2 ** lvl, W // 2 ** lvl)
+            outs.append(t if tuple(t.shape[2:]) == size else F.interpolate(t, size=size))
+        for ds in self.downscalers:
+            outs.append(ds(outs[-1]))
+        return outs

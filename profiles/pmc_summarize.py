@@ -51,6 +51,10 @@ for name in set(fetch) | set(write):
     e["write_MB_per_step"] += write.get(name, [0, 0])[1] / 1024 / steps
 for e in out.values():
     e["traffic_MB_per_launch"] = (e["fetch_MB_per_step_corrected"] + e["write_MB_per_step"]) / max(1.0, e["launches_per_step"])
-json.dump({"steps_analysed": steps, "note": "FETCH_SIZE doubled (gfx950 correction), KB -> MB; bench.py --no-graph, bs 32, 512^2, bf16",
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (source_stamp: ties the figures to the kernel sources they were measured on)
+
+json.dump({"steps_analysed": steps, "source_stamp": bench.source_stamp(), "note": "FETCH_SIZE doubled (gfx950 correction), KB -> MB; bench.py --no-graph, bs 32, 512^2, bf16",
            "kernels": out}, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))

@@ -222,3 +222,104 @@ class ResNetBackbone(nn.Module):
 
 
 TorchvisionBackbone = ResNetBackbone  # same constructor keywords as the reference class for resnets
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# TimmBackbone level contract (reference src/sihl/timm_backbone.py:95-187; BASELINE configs[4]: timm convnext_base).
+# timm is not available offline, so the trunk is this file's own statement of the PUBLISHED ConvNeXt architecture
+# (stem 4x4 / stride 4 + LayerNorm; per stage: [LayerNorm + 2x2 / stride 2 conv between stages,] blocks of depthwise
+# 7x7 -> LayerNorm -> Linear x4 -> GELU -> Linear -> layer scale -> residual), run on PyTorch-ROCm ops: backbones are
+# third-party code in the reference and not a hand-kernel target.  Parity of the trunk against timm is
+# UNPINNED; what IS the reference's own code - and is tested - is the level contract around it.
+CONVNEXTS = {"convnext_tiny": ((3, 3, 9, 3), (96, 192, 384, 768)), "convnext_small": ((3, 3, 27, 3), (96, 192, 384, 768)),
+             "convnext_base": ((3, 3, 27, 3), (128, 256, 512, 1024))}
+
+
+class _LayerNorm2d(nn.LayerNorm):
+    def forward(self, x: Tensor) -> Tensor:  # NCHW in / out, normalised over channels
+        return F.layer_norm(x.permute(0, 2, 3, 1), self.normalized_shape, self.weight, self.bias, self.eps).permute(0, 3, 1, 2)
+
+
+class _ConvNeXtBlock(nn.Module):
+    def __init__(self, dim: int):
+        super().__init__()
+        self.conv_dw = nn.Conv2d(dim, dim, 7, padding=3, groups=dim)
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+        self.fc1, self.act, self.fc2 = nn.Linear(dim, 4 * dim), nn.GELU(), nn.Linear(4 * dim, dim)
+        self.gamma = nn.Parameter(1e-6 * torch.ones(dim))
+
+    def forward(self, x: Tensor) -> Tensor:
+        y = self.conv_dw(x).permute(0, 2, 3, 1)
+        y = self.fc2(self.act(self.fc1(self.norm(y)))) * self.gamma
+        return x + y.permute(0, 3, 1, 2)
+
+
+class _ConvNeXtTrunk(nn.Module):
+    """features_only trunk: forward(x) -> the four stage outputs, at reductions 4, 8, 16, 32 (no stride-2 map)."""
+    reductions = (4, 8, 16, 32)
+
+    def __init__(self, depths, dims, input_channels: int = 3):
+        super().__init__()
+        self.stem = nn.Sequential(nn.Conv2d(input_channels, dims[0], 4, stride=4), _LayerNorm2d(dims[0], eps=1e-6))
+        stages = []
+        for i, (d, c) in enumerate(zip(depths, dims)):
+            down = nn.Identity() if i == 0 else nn.Sequential(_LayerNorm2d(dims[i - 1], eps=1e-6),
+                                                             nn.Conv2d(dims[i - 1], c, 2, stride=2))
+            stages.append(nn.Sequential(down, *[_ConvNeXtBlock(c) for _ in range(d)]))
+        self.stages = nn.ModuleList(stages)
+
+    def forward(self, x: Tensor) -> List[Tensor]:
+        x = self.stem(x)
+        outs = []
+        for s in self.stages:
+            x = s(x)
+            outs.append(x)
+        return outs
+
+
+class TimmBackbone(nn.Module):
+    """Level-list backbone with the reference TimmBackbone's contract (timm_backbone.py:95-187): ``out_channels`` =
+    [input] + one entry per level; a trunk without a stride-2 feature map gets a FAKE level 1 - the (normalised) input
+    nearest-resized to half size (:143-152) - so convnext_base yields [3, 3, 128, 256, 512, 1024]; every trunk output
+    is nearest-resized to (H / 2^level, W / 2^level) (:178-184, a no-op for these trunks); levels above 5 come from
+    AntialiasedDownscaler blocks (:167-171,185-186).  ``depths`` overrides the stage depths (tests)."""
+
+    def __init__(self, name: str = "convnext_base", pretrained: bool = False, input_channels: int = 3,
+                 top_level: int = 5, frozen_levels: int = 0, freeze_batchnorms: bool = False, depths=None):
+        super().__init__()
+        if name not in CONVNEXTS:
+            raise ValueError(f"Architecture {name} is not supported. Select from {tuple(CONVNEXTS)}")
+        if pretrained:
+            raise RuntimeError("pretrained weights need network access, which this environment does not have")
+        self.name, self.top_level = name, top_level
+        d, dims = CONVNEXTS[name]
+        self.model = _ConvNeXtTrunk(depths or d, dims, input_channels)
+        self.normalize = nn.Identity()  # ImageNet normalisation only accompanies pretrained weights (:137-141)
+        self.fake_level1 = 2 not in self.model.reductions
+        min_size = 2 ** (top_level + 1)
+        self.dummy_input = torch.zeros(1, input_channels, min_size, min_size)
+        with torch.no_grad():
+            self.out_channels = [input_channels] + [t.shape[1] for t in self._features(self.dummy_input)]
+        c = self.out_channels[-1]
+        extra = range(top_level - 5)
+        self.out_channels += [c for _ in extra]
+        self.downscalers = nn.ModuleList([AntialiasedDownscaler(c, c) for _ in extra])
+
+    def _features(self, x: Tensor) -> List[Tensor]:
+        feats = self.model(x)
+        if self.fake_level1:
+            feats = [F.interpolate(x, size=(x.shape[2] // 2, x.shape[3] // 2))] + feats
+        return feats
+
+    def forward(self, input: Tensor) -> List[Tensor]:
+        assert input.shape[2] % 2 ** self.top_level == 0
+        assert input.shape[3] % 2 ** self.top_level == 0
+        x = self.normalize(input)
+        H, W = x.shape[2:]
+        outs = [input]
+        for lvl, t in zip(range(1, self.top_level + 1), self._features(x)):
+            size = (H // 2 ** lvl, W // 2 ** lvl)
+            outs.append(t if tuple(t.shape[2:]) == size else F.interpolate(t, size=size))
+        for ds in self.downscalers:
+            outs.append(ds(outs[-1]))
+        return outs

@@ -37,6 +37,23 @@ constexpr int P8_SCR = 4096;                       // per wave: 2 KiB transpose 
 constexpr int P8_LDS = 2 * P8_KTILE + 8 * P8_SCR;  // 163 840 B = all of a CU's LDS
 constexpr int P8_THREADS = 512;
 
+// In-kernel cycle stamps (SIHL_TUNING builds, debug bit 64 only): shares of the loop per segment, per wave.
+#ifdef SIHL_TUNING
+#define P8_STAMP(var)                                                                       \
+  do {                                                                                      \
+    if (dbg & 64) {                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                    \
+      unsigned long long t__;                                                               \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");           \
+      __builtin_amdgcn_sched_barrier(0);                                                    \
+      var += t__ - t_last;                                                                  \
+      t_last = t__;                                                                         \
+    }                                                                                       \
+  } while (0)
+#else
+#define P8_STAMP(var) do {} while (0)
+#endif
+
 #define P8_BAR()                               \
   do {                                         \
     asm volatile("s_barrier" ::: "memory");    \
@@ -291,6 +308,8 @@ __global__ __launch_bounds__(P8_THREADS) void conv_p8_kernel(const ConvParams p)
   const int dbg = SIHL_DBG(p);  // tuning ablations (results invalid): 1 no DMA in the loop, 2 no MFMA, 8 no stagger,
                           // 16 no epilogue; 32 (a valid schedule): one barrier per phase, no stagger
   bool in_loop = false;
+  unsigned long long t_last = 0, t_read = 0, t_issue = 0, t_bar = 0, t_mma = 0, t_wait = 0, t_epi = 0;
+  (void)t_last; (void)t_read; (void)t_issue; (void)t_bar; (void)t_mma; (void)t_wait; (void)t_epi;
   auto issue = [&](int hq) {
     if (hq == 0) advance();
     if (!is_more) return;
@@ -355,6 +374,8 @@ __global__ __launch_bounds__(P8_THREADS) void conv_p8_kernel(const ConvParams p)
   if (wn == 1 && !(dbg & 40)) P8_BAR();  // stagger: waves 4-7 run one barrier behind waves 0-3
   in_loop = true;
 
+  P8_STAMP(t_epi);
+  t_epi = 0;
   for (int g = 0; g < total; ++g) {
     // one K-tile = four phases, fragments from K-tile buffer g & 1
     const char* cb = cbase + (g & 1) * P8_KTILE;
@@ -370,10 +391,15 @@ __global__ __launch_bounds__(P8_THREADS) void conv_p8_kernel(const ConvParams p)
       fp0[u][0] = *(const uint4*)(pb + u * 2048 + loff0);
       fp0[u][1] = *(const uint4*)(pb + u * 2048 + loff1);
     }
+    P8_STAMP(t_read);
     issue(2);
+    P8_STAMP(t_issue);
     if (!(dbg & 32)) P8_BAR();
+    P8_STAMP(t_bar);
     mma_quad(T0(), T0());
+    P8_STAMP(t_mma);
     P8_BAR();
+    P8_STAMP(t_bar);
     // phase 1: (C0, P1).  Every wave's partial statistics of the previous tile are in LDS by now (two barriers ago).
     if (flush_pending) {
       p8_stats_flush(p, smem, flush_tm, flush_n0, tid);
@@ -384,25 +410,39 @@ __global__ __launch_bounds__(P8_THREADS) void conv_p8_kernel(const ConvParams p)
       fp1[u][0] = *(const uint4*)(pb + 2 * P8_HALF + u * 2048 + loff0);
       fp1[u][1] = *(const uint4*)(pb + 2 * P8_HALF + u * 2048 + loff1);
     }
+    P8_STAMP(t_read);
     issue(3);
+    P8_STAMP(t_issue);
     if (!(dbg & 32)) P8_BAR();
+    P8_STAMP(t_bar);
     mma_quad(T0(), T1());
+    P8_STAMP(t_mma);
     P8_BAR();
+    P8_STAMP(t_bar);
     // phase 2: (C1, P1)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       fc[t][0] = *(const uint4*)(cb + 2 * P8_HALF + t * 2048 + loff0);
       fc[t][1] = *(const uint4*)(cb + 2 * P8_HALF + t * 2048 + loff1);
     }
+    P8_STAMP(t_read);
     issue(0);
+    P8_STAMP(t_issue);
     if (!(dbg & 32)) P8_BAR();
+    P8_STAMP(t_bar);
     mma_quad(T1(), T1());
+    P8_STAMP(t_mma);
     P8_BAR();
+    P8_STAMP(t_bar);
     // phase 3: (C1, P0); the next K-tile must have landed - only the two half-tiles issued after it stay in flight
     issue(1);
+    P8_STAMP(t_issue);
     if (is_more) wait_vm_keep<4>(); else wait_vm_keep<0>();
+    P8_STAMP(t_wait);
     if (!(dbg & 32)) P8_BAR();
+    P8_STAMP(t_bar);
     mma_quad(T1(), T0());
+    P8_STAMP(t_mma);
     if (++c_kin == KT) {
       c_kin = 0;
       const int L = wgl + c_k * G;
@@ -418,9 +458,17 @@ __global__ __launch_bounds__(P8_THREADS) void conv_p8_kernel(const ConvParams p)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       ++c_k;
+      P8_STAMP(t_epi);
     }
     P8_BAR();
+    P8_STAMP(t_bar);
   }
+#ifdef SIHL_TUNING
+  if ((dbg & 64) && p.partial && lane == 0) {
+    unsigned long long* o = (unsigned long long*)p.partial + ((long)blockIdx.x * 8 + wave) * 8;
+    o[0] = t_read; o[1] = t_issue; o[2] = t_bar; o[3] = t_mma; o[4] = t_wait; o[5] = t_epi; o[6] = (unsigned long long)total; o[7] = 0;
+  }
+#endif
   if (wn == 0 && !(dbg & 40)) P8_BAR();  // matches the last barrier of the staggered group
   if (flush_pending) p8_stats_flush(p, smem, flush_tm, flush_n0, tid);
 }

@@ -153,6 +153,11 @@ class wgrad_side_stream:
         return False
 
 
+def side_stream_history() -> bool:
+    """True once any side stream has been created in this process (eager two-stream steps have run)."""
+    return bool(_SIDE_STREAMS)
+
+
 def side_stream_in_use():
     """The wgrad side stream if weight gradients have been queued on it since the last join, else None."""
     return _SIDE.stream if _SIDE is not None and _SIDE.dirty else None

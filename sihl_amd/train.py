@@ -388,5 +388,14 @@ class Trainer:
         graph, static_leaves, loss, metrics = entry
         torch._foreach_copy_(static_leaves, leaves)
         graph.replay()  # ... the replay does
+        if images.is_cuda:
+            from sihl_amd import ops
+            if ops.side_stream_history():
+                # Replays queued back to back faulted (GPU memory access fault on the 2nd+ replay) in processes whose
+                # EARLIER eager steps had used the wgrad side stream; with one replay in flight at a time they never did
+                # (profiles/r02_graph_fault_experiments.txt).  The captured graph is the same linear
+                # chain either way, so until the owner of the bad access is known a process with two-stream history
+                # keeps one replay in flight.  (A graph Trainer itself never uses a second stream.)
+                torch.cuda.current_stream().synchronize()
         self._step_scheduler()
         return loss, metrics

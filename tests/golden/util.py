@@ -110,3 +110,18 @@ def caller_batch():
     boxes = [torch.tensor([[5.2, 7.9, 40.3, 33.1], [22.4, 30.6, 58.7, 61.2]]), torch.tensor([[10.5, 12.25, 30.75, 50.5]])]
     classes = [torch.tensor([1, 4]), torch.tensor([2])]
     return x, {"classes": classes, "boxes": boxes}
+
+
+def emulate_bf16_storage(module):
+    """Make a CPU fp32 oracle module keep its activations the way the bf16 HIP path does: every leaf module's output
+    is rounded to bf16 (and carried on as fp32).  Autograd differentiates through the two casts, so the GRADIENT that
+    flows back across the same boundary is rounded to bf16 too - fp32 accumulation inside each op, bf16 storage
+    between ops, fp32 parameter gradients: the arithmetic model of the bf16 kernels.  The deviation of this run from
+    the plain fp32 oracle on the same (bf16-rounded) operands is the noise floor any bf16 implementation lives with."""
+    def hook(_m, _inp, out):
+        if isinstance(out, torch.Tensor) and out.is_floating_point():
+            return out.bfloat16().float()
+        return out
+
+    handles = [m.register_forward_hook(hook) for m in module.modules() if not any(True for _ in m.children())]
+    return handles

@@ -139,7 +139,7 @@ int main(int argc, char** argv) {
     }
     if (getenv("P8_ABLATE")) {
       sihl_conv2d_p8_enable(1); sihl_conv2d_tile_override(256);
-      const int modes[] = {0, 8, 32, 33, 34, 35, 16, 32 | 16, 33 | 16, 34 | 16, 35 | 16};
+      const int modes[] = {0, 32, 33, 34, 35, 32 | 16, 35 | 16};
       for (int dm : modes) {
         sihl_conv2d_debug(dm);
         float best = 1e9f;
@@ -154,6 +154,26 @@ int main(int argc, char** argv) {
         }
         printf("    ablate dbg=%2d (1 noDMA 2 noMFMA 8 nostagger 16 noepi 32 one-barrier): %8.1f us\n", dm, best * 1e3);
       }
+      // cycle shares per segment (debug bit 64): per-wave sums over the launch, averaged over workgroups
+      unsigned long long* dstamp; CK(hipMalloc(&dstamp, 256 * 8 * 8 * 8)); 
+      for (int dm : {64, 64 | 32}) {
+        CK(hipMemset(dstamp, 0, 256 * 8 * 8 * 8));
+        sihl_conv2d_debug(dm);
+        sihl_conv2d_fwd_ws(din[0], dw, nullptr, dout1, s.N, s.H, s.W, s.Cin, s.Cout, s.K, s.K, s.stride, s.pad, 1, 1, 1, nullptr,
+                           nullptr, nullptr, nullptr, 2, dst1, stb, 0, dstamp, 256 * 8 * 8 * 8, 0);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> hs(256 * 8 * 8);
+        CK(hipMemcpy(hs.data(), dstamp, hs.size() * 8, hipMemcpyDeviceToHost));
+        for (int grp = 0; grp < 2; ++grp) {
+          double a[7] = {0, 0, 0, 0, 0, 0, 0}; int n = 0;
+          for (int wg = 0; wg < 256; ++wg) for (int w = grp * 4; w < grp * 4 + 4; ++w) { const unsigned long long* o = &hs[(wg * 8 + w) * 8]; if (!o[6]) continue; for (int k = 0; k < 7; ++k) a[k] += (double)o[k]; ++n; }
+          if (!n) continue;
+          const double kt = a[6] / n;
+          printf("    stamps dbg=%3d waves %d-%d: per K-tile cycles: read %6.0f issue %6.0f barrier %6.0f mma %6.0f vmwait %6.0f | epilogue per tile %8.0f  (K-tiles/WG %.0f)\n",
+                 dm, grp * 4, grp * 4 + 3, a[0] / n / kt, a[1] / n / kt, a[2] / n / kt, a[3] / n / kt, a[4] / n / kt, a[5] / n / (kt / (s.K * s.K * (s.Cin / 64))), kt);
+        }
+      }
+      CK(hipFree(dstamp));
       sihl_conv2d_debug(0);
     }
     sihl_conv2d_p8_enable(1); sihl_conv2d_tile_override(0);
