@@ -125,3 +125,35 @@ def emulate_bf16_storage(module):
 
     handles = [m.register_forward_hook(hook) for m in module.modules() if not any(True for _ in m.children())]
     return handles
+
+
+def emulate_rounding_noise(module, seed):
+    """Like emulate_bf16_storage, but every boundary value is perturbed by a random relative error of bf16's rounding
+    size (uniform in +-2^-8, forward values only) instead of being rounded: ONE rounding pattern is one sample of the
+    noise - gradients that are small differences of large sums (fusion weights, biases in front of a norm) move by very
+    different amounts from pattern to pattern - so the floor of a tensor is taken as the largest deviation over the
+    bf16 emulation and a few such samples."""
+    g = torch.Generator().manual_seed(seed)
+
+    def hook(_m, _inp, out):
+        if isinstance(out, torch.Tensor) and out.is_floating_point():
+            return out * (1 + (torch.rand(out.shape, generator=g) - 0.5) * 2.0 ** -7)
+        return out
+
+    return [m.register_forward_hook(hook) for m in module.modules() if not any(True for _ in m.children())]
+
+
+def bf16_floor(case, ns, data, samples=3):
+    """ref = fp32 oracle on `data`; floor[k] = max over the emulated runs of ||run[k] - ref[k]|| / ||ref[k]||."""
+    _, ref = replay(case, ns, data)
+    runs = [replay(case, ns, data, prepare=lambda m: (emulate_bf16_storage(m), m)[1])[1]]
+    for s in range(samples):
+        runs.append(replay(case, ns, data, prepare=lambda m, s=s: (emulate_rounding_noise(m, 100 + s), m)[1])[1])
+    floor = {}
+    for k, g in ref.items():
+        if g.is_floating_point():
+            n = float(g.float().norm().clamp(min=1e-30))
+            floor[k] = max(float((r[k].float() - g.float()).norm()) / n for r in runs)
+            # the same floor in worst-element terms (largest deviation over the tensor's largest magnitude)
+            floor[k + "|max"] = max(float((r[k].float() - g.float()).abs().max()) for r in runs) / max(1e-6, float(g.abs().max()))
+    return ref, floor

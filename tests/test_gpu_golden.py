@@ -55,10 +55,8 @@ def test_hip_fp32_matches_reference(name):
 BF16_SINGLE = ["cna3x3_train", "cna3x3_eval", "cna1x1_train", "cna1x1_eval", "downscaler_train", "upscaler_train",
                "blurpool_s2", "interpolate_x2", "fusion2", "fusion3"]
 BF16_DEEP = ["bifpn_layer_eval", "bifpn_layer_train", "bifpn_3to7_eval", "bifpn_3to7_train", "od_training_step",
-             "hybrid_3to6_eval", "iseg_training_step", "quad_training_step", "kpt_training_step"]
-# (the training-mode HybridEncoder and DepthEstimation cases are pinned in fp32 only: through their longer SiLU /
-#  BatchNorm chains and the argmin-based chamfer loss, bf16 gradient noise exceeds the 30 % rms criterion calibrated
-#  on the BiFPN stacks - 0.7 rms on the noisiest tensor)
+             "hybrid_3to6_eval", "hybrid_3to6_train", "iseg_training_step", "quad_training_step", "kpt_training_step",
+             "depth_training_step"]
 
 
 def _bf16_pair(name):
@@ -98,15 +96,34 @@ def test_hip_bf16_single_block(name):
 
 @pytest.mark.parametrize("name", BF16_DEEP)
 def test_hip_bf16_deep(name):
-    """Whole BiFPN layers / the detection head's training step in bf16: forward outputs and losses within
-    3e-2 of magnitude; gradients (which pass through many batch-norm + ReLU stages whose intermediate
-    roundings differ from the fp32 oracle) within 30 % rms - the noise floor bf16 training lives with."""
-    res, ref = _bf16_pair(name)
+    """Whole BiFPN stacks / heads' training steps in bf16 against the NOISE FLOOR of bf16 storage, tensor by tensor.
+
+    ref   = fp32 oracle on the bf16-rounded operands;
+    floor = how far an fp32 computation moves from ref when every module boundary carries bf16's rounding error (the
+            oracle with bf16 storage emulated, and three random rounding patterns of the same size:
+            tests/golden/util.bf16_floor) - e.g. 5-15 % rms on the gradients of ONE BiFPN layer, 30-170 % on a few
+            fusion weights of the three-layer stack (differences of large dot products), and unbounded on parameters
+            whose true gradient is zero (a bias in front of a norm);
+    hip   = the bf16 kernels.
+    Every floating result - all gradients, however small the tensor - must lie within 3x its floor + 3 % of its
+    norm; forward outputs and losses additionally within 3e-2 of their magnitude (or twice their own worst-element
+    floor where that is larger: the HybridEncoder's deepest level).  (profiles/r02_bf16_floor.txt has the
+    measured table.)"""
+    import oracle.heads
+    import oracle.layers
+    from util import bf16_floor, namespace_of, quantized_copy
+
+    q = quantized_copy(load_npz(name))
+    ref, floor = bf16_floor(CASES[name], namespace_of(oracle.layers, oracle.heads), q)
+    _, res = replay(CASES[name], _ns(), q, device="cuda", dtype=torch.bfloat16)
+    bad = []
     for k, g in ref.items():
         if not g.is_floating_point():
             continue
-        if k.startswith("g"):
-            if g.numel() >= 16:
-                assert _rms_rel(res[k], g) < 0.3, f"{name}:{k}: rms {_rms_rel(res[k], g):.3e}"
-        else:
-            assert _rel2max(res[k], g) < 3e-2, f"{name}:{k}: {_rel2max(res[k], g):.3e}"
+        err = float((res[k].float() - g.float()).norm() / g.float().norm().clamp(min=1e-30))
+        if err > 3 * floor[k] + 3e-2:
+            bad.append(f"{k} (n={g.numel()}): hip {err:.3e} vs floor {floor[k]:.3e}")
+        if not k.startswith("g"):
+            lim = max(3e-2, 2 * floor[k + "|max"])
+            assert _rel2max(res[k], g) < lim, f"{name}:{k}: {_rel2max(res[k], g):.3e} (limit {lim:.3e})"
+    assert not bad, f"{name}: " + "; ".join(bad)
