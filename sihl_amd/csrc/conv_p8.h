@@ -16,8 +16,12 @@
 //    quadrant per phase: 16 x v_mfma_f32_16x16x32_bf16.  Quadrant order (C0,P0) (C0,P1) (C1,P1) (C1,P0) with the P0
 //    fragments kept in registers: phases read 12 / 4 / 8 / 0 x ds_read_b128, and each half-tile slot is read in
 //    exactly one phase (A0,B0: 0; A1: 1; B1: 2), which is what lets it be restaged two phases later.
-//  * Waves 4-7 run ONE BARRIER behind waves 0-3 (each SIMD hosts one wave of each group): while one group multiplies,
-//    its SIMD partner reads fragments and issues DMA.  Two barriers per phase.
+//  * Barriers: ONE per phase (every wave reads its fragments, multiplies, and meets the others at the end of the
+//    phase; the two waves of a SIMD drift apart between barriers and cover each other's LDS and DMA-issue time), and
+//    the phase's half-tile DMA is issued behind the first eight MFMAs.  Measured on L3 3x3 (profiles/
+//    r02_p8_ablation.txt): the template's two-barrier schedule with waves 4-7 staggered one barrier behind waves 0-3 -
+//    kept under tuning bits 32 / 256 - is 10 % slower here; in-kernel stamps put 35-40 % of a K-tile into barrier
+//    waits and 20 % into issuing the eight LDS-DMA instructions per wave (~200 cycles each), not into waiting for data.
 //  * Operands are swapped - weights are the MFMA's A (row) operand, pixels the B (column) operand - so a lane holds
 //    FOUR CONSECUTIVE CHANNELS of one pixel per accumulator tile.  The epilogue packs them to bf16 (8 bytes), transposes
 //    through a wave-PRIVATE 2 KiB LDS scratch (no workgroup barrier) and stores whole 128-byte pixel rows with 16-byte
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(P8_THREADS) void conv_p8_kernel(const ConvParams p)
     n_tapbit = 1u << is_tap;
   };
   // half-tile hq of the K-tile the issuer stands on: 0 = A0, 1 = B0, 2 = A1, 3 = B1 (LDS order inside a K-tile buffer)
-  const int dbg = SIHL_DBG(p);  // tuning ablations (results invalid): 1 no DMA in the loop, 2 no MFMA, 8 no stagger,
+  const int dbg = SIHL_DBG(p) ^ (32 | 256);  // shipped schedule: one barrier per phase, DMA issued behind the first MFMAs  // tuning ablations (results invalid): 1 no DMA in the loop, 2 no MFMA, 8 no stagger,
                           // 16 no epilogue; 32 (a valid schedule): one barrier per phase, no stagger
   bool in_loop = false;
   unsigned long long t_last = 0, t_read = 0, t_issue = 0, t_bar = 0, t_mma = 0, t_wait = 0, t_epi = 0;
@@ -345,12 +349,12 @@ __global__ __launch_bounds__(P8_THREADS) void conv_p8_kernel(const ConvParams p)
   bool flush_pending = false;
   int flush_tm = 0, flush_n0 = 0;
 
-  auto mma_quad = [&](auto hc_tag, auto h_tag) {
+  auto mma_quad = [&](auto hc_tag, auto h_tag, int hq_inside) {
     constexpr int HC = decltype(hc_tag)::value, HH = decltype(h_tag)::value;
-    if (dbg & 2) return;
+    if (dbg & 2) { if (hq_inside >= 0) issue(hq_inside); return; }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -359,8 +363,15 @@ __global__ __launch_bounds__(P8_THREADS) void conv_p8_kernel(const ConvParams p)
           acc[HC * 4 + t][HH * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
               __builtin_bit_cast(bf16x8_t, fc[t][ks]), __builtin_bit_cast(bf16x8_t, b), acc[HC * 4 + t][HH * 2 + u], 0, 0, 0);
         }
+      if (ks == 0 && hq_inside >= 0) {  // tuning bit 256: the half-tile's DMA goes out behind the first 8 MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        issue(hq_inside);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     __builtin_amdgcn_s_setprio(0);
   };
+  const bool dma_inside = (dbg & 256) != 0;
   using T0 = std::integral_constant<int, 0>;
   using T1 = std::integral_constant<int, 1>;
 
@@ -373,6 +384,7 @@ __global__ __launch_bounds__(P8_THREADS) void conv_p8_kernel(const ConvParams p)
   P8_BAR();
   if (wn == 1 && !(dbg & 40)) P8_BAR();  // stagger: waves 4-7 run one barrier behind waves 0-3
   in_loop = true;
+  if ((dbg & 128) && wn == 1) __builtin_amdgcn_s_setprio(1);  // tuning bit 128: the younger waves of each SIMD
 
   P8_STAMP(t_epi);
   t_epi = 0;
@@ -392,11 +404,11 @@ __global__ __launch_bounds__(P8_THREADS) void conv_p8_kernel(const ConvParams p)
       fp0[u][1] = *(const uint4*)(pb + u * 2048 + loff1);
     }
     P8_STAMP(t_read);
-    issue(2);
+    if (!dma_inside) issue(2);
     P8_STAMP(t_issue);
     if (!(dbg & 32)) P8_BAR();
     P8_STAMP(t_bar);
-    mma_quad(T0(), T0());
+    mma_quad(T0(), T0(), dma_inside ? 2 : -1);
     P8_STAMP(t_mma);
     P8_BAR();
     P8_STAMP(t_bar);
@@ -411,11 +423,11 @@ __global__ __launch_bounds__(P8_THREADS) void conv_p8_kernel(const ConvParams p)
       fp1[u][1] = *(const uint4*)(pb + 2 * P8_HALF + u * 2048 + loff1);
     }
     P8_STAMP(t_read);
-    issue(3);
+    if (!dma_inside) issue(3);
     P8_STAMP(t_issue);
     if (!(dbg & 32)) P8_BAR();
     P8_STAMP(t_bar);
-    mma_quad(T0(), T1());
+    mma_quad(T0(), T1(), dma_inside ? 3 : -1);
     P8_STAMP(t_mma);
     P8_BAR();
     P8_STAMP(t_bar);
@@ -426,11 +438,11 @@ __global__ __launch_bounds__(P8_THREADS) void conv_p8_kernel(const ConvParams p)
       fc[t][1] = *(const uint4*)(cb + 2 * P8_HALF + t * 2048 + loff1);
     }
     P8_STAMP(t_read);
-    issue(0);
+    if (!dma_inside) issue(0);
     P8_STAMP(t_issue);
     if (!(dbg & 32)) P8_BAR();
     P8_STAMP(t_bar);
-    mma_quad(T1(), T1());
+    mma_quad(T1(), T1(), dma_inside ? 0 : -1);
     P8_STAMP(t_mma);
     P8_BAR();
     P8_STAMP(t_bar);
@@ -441,7 +453,7 @@ __global__ __launch_bounds__(P8_THREADS) void conv_p8_kernel(const ConvParams p)
     P8_STAMP(t_wait);
     if (!(dbg & 32)) P8_BAR();
     P8_STAMP(t_bar);
-    mma_quad(T1(), T0());
+    mma_quad(T1(), T0(), -1);
     P8_STAMP(t_mma);
     if (++c_kin == KT) {
       c_kin = 0;

@@ -139,7 +139,7 @@ int main(int argc, char** argv) {
     }
     if (getenv("P8_ABLATE")) {
       sihl_conv2d_p8_enable(1); sihl_conv2d_tile_override(256);
-      const int modes[] = {0, 32, 33, 34, 35, 32 | 16, 35 | 16};
+      const int modes[] = {0, 32, 32 | 128, 32 | 256, 32 | 128 | 256, 256, 128 | 256, 32 | 16, 32 | 16 | 256};
       for (int dm : modes) {
         sihl_conv2d_debug(dm);
         float best = 1e9f;
@@ -152,11 +152,11 @@ int main(int argc, char** argv) {
           float ms; CK(hipEventElapsedTime(&ms, e0, e1));
           if (r) best = std::min(best, ms / 10);
         }
-        printf("    ablate dbg=%2d (1 noDMA 2 noMFMA 8 nostagger 16 noepi 32 one-barrier): %8.1f us\n", dm, best * 1e3);
+        printf("    ablate dbg=%2d (16 noepi 32 one-barrier 128 prio-w4-7 256 dma-in-mma): %8.1f us\n", dm, best * 1e3);
       }
       // cycle shares per segment (debug bit 64): per-wave sums over the launch, averaged over workgroups
       unsigned long long* dstamp; CK(hipMalloc(&dstamp, 256 * 8 * 8 * 8)); 
-      for (int dm : {64, 64 | 32}) {
+      for (int dm : {64 | 32, 64 | 32 | 256}) {
         CK(hipMemset(dstamp, 0, 256 * 8 * 8 * 8));
         sihl_conv2d_debug(dm);
         sihl_conv2d_fwd_ws(din[0], dw, nullptr, dout1, s.N, s.H, s.W, s.Cin, s.Cout, s.K, s.K, s.stride, s.pad, 1, 1, 1, nullptr,
