@@ -194,6 +194,13 @@ int sihl_maxpool3x3s2_bwd(const void* dy, const void* idx, void* dx, int N, int 
                           hipStream_t stream);
 
 /* ---- MLP hidden layers: y = act(LayerNorm(z)*gamma + beta) over [rows][C] (object_detection.py:51-61) ----- */
+/* Linear -> LayerNorm -> activation of one MLP layer in ONE launch (heads/object_detection.py:51-61):
+ * y = act(LayerNorm(x W^T + b) * gamma + beta), x [rows][Cin], w [Cout][Cin], Cout <= 256.  z (nullable) = the Linear's
+ * output, mean / rstd (nullable, together) = row statistics - what sihl_layernorm_act_bwd reads.  Same arithmetic as
+ * sihl_conv2d_fwd followed by sihl_layernorm_act. */
+int sihl_linear_ln_act(const void* x, const void* w, const float* bias, const float* gamma, const float* beta, float eps,
+                       int act, void* z, void* y, float* mean, float* rstd, long rows, int Cin, int Cout, int dtype,
+                       hipStream_t stream);
 int sihl_layernorm_act(const void* z, void* y, long rows, int C, const float* gamma, const float* beta, float eps,
                        int act, float* mean, float* rstd, int dtype, hipStream_t stream);
 int sihl_layernorm_bwd_waves(long rows); /* workgroups = partial rows of the backward (workspace sizing) */

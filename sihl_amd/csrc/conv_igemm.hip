@@ -215,6 +215,58 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t
     }
     return;
   }
+  if constexpr (BN == 256 && !ADD) if (p.ln_gamma) {
+    // Linear -> LayerNorm -> act: one tile row is one output row (n0 == 0, Cout <= 256).  A row's 16-byte chunks sit on
+    // consecutive lanes (32 lanes for bf16, the whole wave for fp32), so the two row reductions are lane shuffles; same
+    // arithmetic as layernorm_act_kernel (two-pass variance, 1 / sqrt, hardware exp2 / rcp sigmoid) on the same staged
+    // values, so fused and unfused agree bit for bit in what they normalise.
+    static_assert(BM * CHUNKS % NTHREADS == 0, "every lane takes part in every row reduction");
+    static_assert(NTHREADS % CHUNKS == 0, "a thread keeps its channel chunk: gamma / beta live in registers");
+    T* __restrict__ yo = (T*)p.ln_out;
+    const float inv_c = 1.f / (float)p.Cout;
+    const int ch = tid % CHUNKS, co = ch * VEC;
+    const bool cok = co < p.Cout;  // Cout % VEC == 0
+    float ga[VEC], be[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { ga[e] = cok ? p.ln_gamma[co + e] : 0.f; be[e] = cok ? p.ln_beta[co + e] : 0.f; }
+    for (int idx = tid; idx < BM * CHUNKS; idx += NTHREADS) {
+      const int row = idx / CHUNKS;
+      const int m = m0 + row;
+      float v[VEC];
+      const uint4 raw = *(const uint4*)(epi + row * EPI_STRIDE + ch * 16);
+      unpack16(raw, v, T());
+      float sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { v[e] = cok ? v[e] : 0.f; sum += v[e]; }
+#pragma unroll
+      for (int o = CHUNKS / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      const float mu = sum * inv_c;
+      float q = 0.f;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { const float d = cok ? v[e] - mu : 0.f; q += d * d; }
+#pragma unroll
+      for (int o = CHUNKS / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
+      const float rs = 1.f / sqrtf(q * inv_c + p.ln_eps);
+      if (m < p.M && cok) {
+        float y[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float t = (v[e] - mu) * rs * ga[e] + be[e];
+          if (p.ln_act == SIHL_ACT_SILU) {
+            const float ex = __builtin_amdgcn_exp2f(fminf(-t * 1.4426950408889634f, 126.f));  // = fast_sigmoid
+            t = t * __builtin_amdgcn_rcpf(1.f + ex);
+          } else if (p.ln_act == SIHL_ACT_RELU) {
+            t = fmaxf(t, 0.f);
+          }
+          y[e] = t;
+        }
+        *(uint4*)(yo + (long)m * p.Cout + co) = pack16(y, T());
+        if (out) *(uint4*)(out + (long)m * p.Cout + co) = raw;
+        if (ch == 0 && p.ln_mean) { p.ln_mean[m] = mu; p.ln_rstd[m] = rs; }
+      }
+    }
+    return;
+  }
   if (vec_ok && p.out_s == 1 && p.out_image_stride == (long)hw_o * p.Cout) {
     // dense output: row m starts at m * Cout (no per-chunk division by the image size)
     for (int idx = tid; idx < BM * CHUNKS; idx += NTHREADS) {
@@ -967,6 +1019,14 @@ int dispatch(const ConvParams& p, hipStream_t stream) {
   const long in_bytes = (long)p.N * p.H * p.W * p.Cin * (long)sizeof(T);
   const long wt_bytes = (long)p.Cout * p.KH * p.KW * p.Cin * (long)sizeof(T);
   const bool dma = !g_force_reg && in_bytes < (1L << 31) && wt_bytes < (1L << 31) && p.KH * p.KW <= 32;
+  if (p.ln_gamma) {  // fused LayerNorm epilogue: the tile must hold whole rows
+    if (!dma || p.Cout > 256 || p.splits != 1) return SIHL_EARG;
+    const long wgs = (p.M + 127) / 128;
+    if (wgs <= 256) return launch_dma<T, 128, 256, 2, 2, 3>(p, stream);  // alone on its CU: three stages (144 KiB)
+    // big grids: ONE stage (66-132 KiB with the epilogue staging), so that two workgroups share a CU and one's row
+    // normalisation runs under the other's loads and multiplies (the thin-K pointwise rule of stages_for)
+    return launch_dma<T, 128, 256, 2, 2, 1>(p, stream);
+  }
   if (!dma) {
     if (p.Cout > 128) return launch_reg<T, 256, 2, 2>(p, stream);
     if (p.Cout > 64) return launch_reg<T, 128, 2, 2>(p, stream);
@@ -1101,8 +1161,40 @@ int sihl_conv2d_fwd_ws(const void* in, const void* wt, const float* bias, void* 
   }
   p.splits = 1; p.partial = (float*)ws; p.partial_bytes = ws ? ws_bytes : 0;
   p.add = nullptr; p.add_stride = 1; p.add_H = p.add_W = 0;
+  p.ln_gamma = p.ln_beta = nullptr; p.ln_out = nullptr; p.ln_mean = p.ln_rstd = nullptr; p.ln_eps = 0.f; p.ln_act = 0;
   p.w_ntaps = KH * KW; p.w_kw = KW; p.w_ky0 = p.w_kx0 = 0; p.w_kys = p.w_kxs = 1;
   p.out_s = 1; p.out_py = p.out_px = 0; p.out_W = p.Wo;
+  if (dtype == SIHL_F32) return dispatch<float>(p, stream);
+  if (dtype == SIHL_BF16) return dispatch<bf16_t>(p, stream);
+  return SIHL_EARG;
+}
+
+// y = act(LayerNorm(x W^T + b) * gamma + beta) over rows in ONE launch (the MLP layer of the dense heads:
+// torchvision.ops.MLP = Linear -> LayerNorm -> SiLU, heads/object_detection.py:51-61).  x [rows][Cin], w [Cout][Cin],
+// Cout <= 256 and a multiple of the 16-byte vector.  z (nullable) receives the Linear's output (what the backward's
+// LayerNorm gradient reads), mean / rstd (nullable) the row statistics.  act: SIHL_ACT_NONE / RELU / SILU.
+int sihl_linear_ln_act(const void* x, const void* w, const float* bias, const float* gamma, const float* beta, float eps,
+                       int act, void* z, void* y, float* mean, float* rstd, long rows, int Cin, int Cout, int dtype,
+                       hipStream_t stream) {
+  if (!x || !w || !gamma || !beta || !y || rows <= 0 || rows > (1L << 30) || Cin <= 0 || Cout <= 0 || Cout > 256)
+    return SIHL_EARG;
+  if (act != SIHL_ACT_NONE && act != SIHL_ACT_RELU && act != SIHL_ACT_SILU) return SIHL_EARG;
+  if (Cout % (dtype == SIHL_BF16 ? 8 : 4)) return SIHL_EARG;
+  if ((mean == nullptr) != (rstd == nullptr)) return SIHL_EARG;
+  ConvParams p;
+  p.in = x; p.wt = w; p.out = z; p.bias = bias;
+  p.pre_scale = p.pre_shift = p.post_scale = p.post_shift = nullptr;
+  p.stats = nullptr;
+  p.N = 1; p.H = 1; p.W = (int)rows; p.Cin = Cin; p.Cout = Cout; p.KH = p.KW = 1;
+  p.stride = 1; p.pad = 0; p.dil = 1; p.Ho = 1; p.Wo = (int)rows; p.M = (int)rows;
+  p.act = SIHL_ACT_NONE; p.stats_mode = 0;
+  p.gridM = p.gridN = 0; p.in_dilate = 1; p.dbg = 0;
+  p.out_image_stride = (long)rows * Cout;
+  p.splits = 1; p.partial = nullptr; p.partial_bytes = 0;
+  p.add = nullptr; p.add_stride = 1; p.add_H = p.add_W = 0;
+  p.w_ntaps = 1; p.w_kw = 1; p.w_ky0 = p.w_kx0 = 0; p.w_kys = p.w_kxs = 1;
+  p.out_s = 1; p.out_py = p.out_px = 0; p.out_W = (int)rows;
+  p.ln_gamma = gamma; p.ln_beta = beta; p.ln_out = y; p.ln_mean = mean; p.ln_rstd = rstd; p.ln_eps = eps; p.ln_act = act;
   if (dtype == SIHL_F32) return dispatch<float>(p, stream);
   if (dtype == SIHL_BF16) return dispatch<bf16_t>(p, stream);
   return SIHL_EARG;
@@ -1160,6 +1252,7 @@ int sihl_conv2d_dgrad_add(const void* dout, const void* wt_t, void* din, const v
   p.add = add;
   p.add_stride = add ? add_stride : 1;
   p.add_H = (H + add_stride - 1) / add_stride; p.add_W = (W + add_stride - 1) / add_stride;
+  p.ln_gamma = p.ln_beta = nullptr; p.ln_out = nullptr; p.ln_mean = p.ln_rstd = nullptr; p.ln_eps = 0.f; p.ln_act = 0;
   p.w_ntaps = KH * KW; p.w_kw = KW; p.w_ky0 = p.w_kx0 = 0; p.w_kys = p.w_kxs = 1;
   p.out_s = 1; p.out_py = p.out_px = 0; p.out_W = W;
   // 3x3 / stride 2 / pad 1 (the strided convs of the ResNet stages): four parity classes of output pixels, each a small

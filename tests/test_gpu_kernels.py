@@ -148,6 +148,52 @@ def test_fuse_up2_and_blur(dtype, rtol, atol):
 
 
 @pytest.mark.parametrize("dtype,rtol,atol", DTYPES)
+def test_linear_ln_act_fused_layer(dtype, rtol, atol):
+    """One MLP layer (Linear -> LayerNorm -> SiLU, heads/object_detection.py:51-61) as ONE launch against (a) the
+    unfused kernel pair - the same arithmetic on the same stored values: equal to summation-order rounding - and (b) a
+    plain fp32 PyTorch computation, forward and all five gradients; rows cover partial last tiles, a grid above and
+    below one workgroup per CU, and a narrow head (32 channels: the golden cases' width)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    for rows, cin, cout in [(300, 256, 256), (5456 * 8, 256, 256), (1000, 64, 32), (129, 32, 32)]:
+        x = torch.randn(rows, cin, generator=g).to(dtype).float().requires_grad_(True)
+        w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).requires_grad_(True)
+        b = torch.randn(cout, generator=g).requires_grad_(True)
+        ga = (1 + 0.3 * torch.randn(cout, generator=g)).requires_grad_(True)
+        be = (0.3 * torch.randn(cout, generator=g)).requires_grad_(True)
+        z = F.linear(x, w.to(dtype).float(), b)
+        if dtype == torch.bfloat16:
+            z = z.bfloat16().float()  # the pre-norm row is stored in the compute dtype in both GPU variants
+        ref = F.silu(F.layer_norm(z, (cout,), ga, be))
+        cot = torch.randn(ref.shape, generator=g).to(dtype).float()
+        ref.backward(cot)
+        outs = []
+        for fused in (True, False):
+            xd = x.detach().to(DEV, dtype).requires_grad_(True)
+            ps = [t.detach().to(DEV).requires_grad_(True) for t in (w, b, ga, be)]
+            assert ops.linear_ln_act_fusable(xd, ps[0])
+            if fused:
+                y = ops.linear_ln_act(xd, ps[0], ps[1], ps[2], ps[3], 1e-5, "silu")
+            else:
+                y = ops.layernorm_act(ops.linear(xd, ps[0], ps[1]), ps[2], ps[3], 1e-5, "silu")
+            y.backward(cot.to(DEV, dtype))
+            outs.append([y] + [xd.grad] + [p_.grad for p_ in ps])
+        names = ["y", "dx", "dw", "db", "dgamma", "dbeta"]
+        refs = [ref, x.grad, w.grad, b.grad, ga.grad, be.grad]
+        for n, a, c, r in zip(names, outs[0], outs[1], refs):
+            _close(a, c, 1e-5 if dtype == torch.float32 else 1e-2, 1e-5 if dtype == torch.float32 else 1e-2, f"fused vs unfused {n} {rows}x{cin}>{cout}")
+            _close(a, r, rtol * 2, atol * 2, f"fused vs torch {n} {rows}x{cin}>{cout}")
+    # inference: no pre-norm rows, no statistics written
+    with torch.no_grad():
+        xd = torch.randn(777, 256, generator=g).to(DEV, dtype)
+        wd, bd = (torch.randn(256, 256, generator=g) / 16).to(DEV), torch.randn(256, generator=g).to(DEV)
+        gd, bed = torch.ones(256, device=DEV), torch.zeros(256, device=DEV)
+        a = ops.linear_ln_act(xd, wd, bd, gd, bed, 1e-5, "silu")
+        c = ops.layernorm_act(ops.linear(xd, wd, bd), gd, bed, 1e-5, "silu")
+        _close(a, c, 1e-5 if dtype == torch.float32 else 1e-2, 1e-5 if dtype == torch.float32 else 1e-2, "eval fused vs unfused")
+
+
+@pytest.mark.parametrize("dtype,rtol,atol", DTYPES)
 def test_linear_layernorm(dtype, rtol, atol):
     ops = _ops()
     g = torch.Generator().manual_seed(2)
