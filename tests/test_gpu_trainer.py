@@ -148,6 +148,47 @@ def test_wgrad_side_stream_gives_identical_gradients(mode):
     assert ops._SIDE is None  # the context manager restored the single-stream state
 
 
+def test_side_stream_is_refused_for_weights_autograd_would_copy():
+    """Weight gradients written by the side stream are handed to autograd while that stream may still be writing them,
+    which is safe only while AccumulateGrad takes the tensor as it is.  A model whose conv weights are NOT stored
+    channels_last (model.cuda() without .to(memory_format=channels_last)) would make autograd launch a layout copy on the
+    main stream: the Trainer must keep such a model single-stream (with a warning) - and its gradients must equal the
+    channels_last model's."""
+    import warnings
+
+    import sihl_amd
+    from sihl_amd.train import Trainer
+
+    ref_model = _model()  # channels_last
+    torch.manual_seed(0)
+    backbone = sihl_amd.ResNetBackbone("resnet18", top_level=5)
+    neck = sihl_amd.layers.BiFPN(backbone.out_channels, 32, 3, 6, num_layers=1)
+    head = sihl_amd.heads.ObjectDetection(neck.out_channels, num_classes=5, bottom_level=3, top_level=6, num_channels=32)
+    nchw_model = sihl_amd.SihlModel(backbone, neck, [head]).cuda()  # weights left NCHW-contiguous
+    nchw_model.load_state_dict(ref_model.state_dict())
+    assert any(p.dim() == 4 and p.shape[2] > 1 and not p.is_contiguous(memory_format=torch.channels_last)
+               for p in nchw_model.parameters())
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        tr = Trainer(nchw_model, lr=LR, wgrad_stream="all")
+    assert tr.wgrad_stream == "off" and any("channels_last" in str(x.message) for x in w)
+    ref_tr = Trainer(ref_model, lr=LR, wgrad_stream="all")
+    assert ref_tr.wgrad_stream == "all"
+    images, targets = _batch(3, (2, 1, 3))
+    out = []
+    for t, m in ((tr, nchw_model), (ref_tr, ref_model)):
+        m.train()
+        t.optimizer.zero_grad(set_to_none=True)
+        loss, _ = t.forward_loss(images, targets)
+        t._backward(loss)
+        torch.cuda.synchronize()
+        out.append({n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert set(out[0]) == set(out[1])
+    for n in out[0]:
+        scale = float(out[1][n].abs().max()) + 1e-12
+        assert float((out[0][n] - out[1][n]).abs().max()) <= 1e-4 * scale, n
+
+
 def test_multi_gpu_code_path_on_one_rank_matches_plain_step():
     """The data-parallel step (gradient buckets filled from grad-ready hooks, packed on the wgrad side stream, RCCL
     all-reduce on the collective's stream, averages scattered back) run in a process group of ONE rank must train
