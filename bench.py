@@ -231,6 +231,10 @@ def main():
     ap.add_argument("--graph-warmup-stream", default="off", choices=["off", "small", "all"],
                     help="debugging only, with --graph: stream mode of the eager warm-up steps before the capture (the "
                          "round-1 fault needed 'all'; a graph Trainer otherwise never uses a second stream)")
+    ap.add_argument("--no-fused-loss", action="store_true",
+                    help="A/B: the detection loss as PyTorch device ops instead of the fused sihl_od_loss kernel")
+    ap.add_argument("--lean", action="store_true",
+                    help="profiling passes: skip the north-star probe, the sub-metrics and the yardsticks")
     ap.add_argument("--extra-stream", action="store_true",
                     help="debugging: create a second HIP stream and run one trivial kernel on it before the warm-up")
     ap.add_argument("--sync-warmup", action="store_true", help="debugging: synchronize after every warm-up step")
@@ -281,6 +285,9 @@ def main():
 
     import types
 
+    if args.no_fused_loss:
+        from sihl_amd.heads import object_detection as _od
+        _od.FUSED_LOSS = False
     hip_ns = types.SimpleNamespace(ResNetBackbone=sihl_amd.ResNetBackbone, BiFPN=sihl_amd.layers.BiFPN,
                                    ObjectDetection=sihl_amd.heads.ObjectDetection, SihlModel=sihl_amd.SihlModel)
     model = build_model(hip_ns, device, native_backbone=args.backbone == "native")
@@ -344,7 +351,7 @@ def main():
     fwd = None
     sub = None
     peaks = None
-    if world == 1 and rank == 0 and not args.rehearse_dp:
+    if world == 1 and rank == 0 and not args.rehearse_dp and not args.lean:
         fwd = north_star_forward(model, device, amp or torch.float32, args.batch, args.size)
         trace("north-star forward probe done")
         # sub-metrics of the same step: forward only, and forward + backward without clip / optimizer

@@ -213,6 +213,18 @@ int sihl_layernorm_act_bwd(const void* z, const void* dy, void* dz, long rows, i
 long sihl_colsum_ws_bytes(long rows, int C);
 int sihl_colsum(const void* x, long rows, int C, float* out, int dtype, float* ws, long ws_bytes, hipStream_t stream);
 
+/* ---- ObjectDetection.training_step loss (heads/object_detection.py:157-208): the four loss sums and their gradients
+ * with respect to the head's outputs in one pass over the matching's target tensors.  loc / iou [n_positions], box
+ * [n_rows][4], cls [n_rows][C] in `dtype`; targets fp32, tgt_cls int64; loc_norm / iou_norm / wsum / none_matched (bool)
+ * are DEVICE scalars.  losses[5] = total, location, box, class, iou; d_* = gradients of the total.  ws:
+ * sihl_od_loss_ws_bytes. */
+long sihl_od_loss_ws_bytes(long n_positions, int n_rows);
+int sihl_od_loss(const void* loc, const void* iou, const void* box, const void* cls, const float* loc_target,
+                 const float* rel_iou, const float* cand_off, const float* cand_scale, const float* tgt_box,
+                 const float* wts, const long* tgt_cls, const float* loc_norm, const float* iou_norm, const float* wsum,
+                 const void* none_matched, long n_positions, int n_rows, int C, void* d_loc, void* d_iou, void* d_box,
+                 void* d_cls, float* losses, int dtype, float* ws, long ws_bytes, hipStream_t stream);
+
 /* ---- ObjectDetection.forward decode (heads/object_detection.py:99-122, anchors :83-97) ---------------------
  * topk_rows : per image, the K largest of P position logits (estride elements apart), sorted descending
  *             (object_detection.py:109); vals fp32 [B][K], idx int32 [B][K].

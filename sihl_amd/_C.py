@@ -27,6 +27,8 @@ SIGNATURES = {
     "sihl_conv2d_debug": (I, [I]),
     "sihl_conv2d_strided_classes_enable": (I, [I]),
     "sihl_conv2d_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, P, P, P, I, P, L, L, P]),
+    "sihl_od_loss_ws_bytes": (L, [L, I]),
+    "sihl_od_loss": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, P, P, P, P, P, I, P, L, P]),
     "sihl_linear_ln_act": (I, [P, P, P, P, P, F, I, P, P, P, P, L, I, I, I, P]),
     "sihl_conv2d_dgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "sihl_conv2d_ws_bytes": (L, [I, I, I, I, I, I, I, I, I, I]),

@@ -234,6 +234,155 @@ __global__ void od_anchors_kernel(Levels lv, int P, float* __restrict__ offsets,
   scales[(long)i * 4 + 0] = -hx; scales[(long)i * 4 + 1] = -hy; scales[(long)i * 4 + 2] = hx; scales[(long)i * 4 + 3] = hy;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Detection loss (ObjectDetection.training_step, src/sihl/heads/object_detection.py:157-208) in one pass: the four loss
+// sums AND their gradients with respect to the head's outputs, from the target-only tensors of the matching.
+//   location  BCE-with-logits(loc_logits, rel_iou == 1).sum() / loc_norm                                   (:157-163)
+//   iou       MSE(iou_preds, rel_iou).sum() / iou_norm                                                      (:175-180)
+//   box       (w * CIoU_loss(offsets + scales * exp(box_raw), gt / full)).sum() / wsum, x10 in the total    (:186-197)
+//   class     (w * CE(cls_logits, gt class)).sum() / wsum                                                   (:199-208)
+// over the fixed-size candidate rows of the matching (w = rel_iou where the anchor's assigned ground truth is the
+// candidate's, 0 otherwise).  Every gradient is elementwise given the normalisers (inputs), so the backward needs no
+// second pass: d_loc / d_iou / d_box / d_cls are written here, for an upstream gradient of 1.
+// CIoU follows torchvision's complete_box_iou_loss (published definition): alpha is a constant in the
+// gradient; max / min pass the gradient to the larger / smaller argument (half each on ties, as ATen does).
+struct OdLossArgs {
+  const void *loc, *iou, *box, *cls;                 // head outputs: [N1], [N1], [R][4], [R][C]
+  const float *loc_target, *rel_iou;                 // [N1]
+  const float *cand_off, *cand_scale, *tgt_box, *wts;  // [R][4] x3, [R]
+  const long* tgt_cls;                               // [R]
+  const float *loc_norm, *iou_norm, *wsum;           // device scalars
+  const bool* none_matched;                          // device scalar
+  void *d_loc, *d_iou, *d_box, *d_cls;
+  float* partial;                                    // [blocks][4]
+  long N1; int R, C;
+};
+
+__device__ __forceinline__ float gmax_w(float a, float b) { return a > b ? 1.f : (a == b ? 0.5f : 0.f); }  // d max(a,b)/da
+
+template <typename T>
+__global__ __launch_bounds__(256) void od_loss_kernel(const OdLossArgs a) {
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const float keep = *a.none_matched ? 0.f : 1.f;  // degenerate ground truths only: the total is the location loss
+  float s_loc = 0.f, s_iou = 0.f, s_box = 0.f, s_cls = 0.f;
+  if (gid < a.N1) {
+    const float x = elem<T>::ld((const T*)a.loc + gid), t = a.loc_target[gid];
+    s_loc = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+    elem<T>::st((T*)a.d_loc + gid, (1.f / (1.f + expf(-x)) - t) / *a.loc_norm);
+    const float q = elem<T>::ld((const T*)a.iou + gid), r = a.rel_iou[gid], d = q - r;
+    s_iou = d * d;
+    elem<T>::st((T*)a.d_iou + gid, keep * 2.f * d / *a.iou_norm);
+  }
+  if (gid < a.R) {
+    const int r = (int)gid;
+    const float w = a.wts[r], inv_wsum = 1.f / *a.wsum;
+    // ---- box: pred = off + scale * exp(raw)
+    float raw[4], e[4], b[4], g[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      raw[k] = elem<T>::ld((const T*)a.box + r * 4 + k);
+      e[k] = expf(raw[k]);
+      b[k] = a.cand_off[r * 4 + k] + a.cand_scale[r * 4 + k] * e[k];
+      g[k] = a.tgt_box[r * 4 + k];
+    }
+    const float eps = 1e-7f;
+    const float x1 = b[0], y1 = b[1], x2 = b[2], y2 = b[3], X1 = g[0], Y1 = g[1], X2 = g[2], Y2 = g[3];
+    const float xk1 = fmaxf(x1, X1), yk1 = fmaxf(y1, Y1), xk2 = fminf(x2, X2), yk2 = fminf(y2, Y2);
+    const bool valid = yk2 > yk1 && xk2 > xk1;
+    const float iw = xk2 - xk1, ih = yk2 - yk1;
+    const float inter = valid ? iw * ih : 0.f;
+    const float pw = x2 - x1, ph = y2 - y1, gw = X2 - X1, gh = Y2 - Y1;
+    const float uni = pw * ph + gw * gh - inter, ue = uni + eps;
+    const float iouv = inter / ue;
+    const float xc1 = fminf(x1, X1), yc1 = fminf(y1, Y1), xc2 = fmaxf(x2, X2), yc2 = fmaxf(y2, Y2);
+    const float cw = xc2 - xc1, chh = yc2 - yc1, c2 = cw * cw + chh * chh + eps;
+    const float sx = 0.5f * ((x1 + x2) - (X1 + X2)), sy = 0.5f * ((y1 + y2) - (Y1 + Y2));
+    const float rho2 = sx * sx + sy * sy;
+    const float kv = 4.f / (3.14159265358979323846f * 3.14159265358979323846f);
+    const float da = atanf(gw / gh) - atanf(pw / ph);
+    const float v = kv * da * da;
+    const float alpha = v / (1.f - iouv + v + eps);
+    s_box = w * (1.f - iouv + rho2 / c2 + alpha * v);
+    // gradient with respect to (x1, y1, x2, y2)
+    float dint[4] = {0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+      dint[0] = -ih * gmax_w(x1, X1);  // xk1 = max(x1, X1)
+      dint[1] = -iw * gmax_w(y1, Y1);
+      dint[2] = ih * gmax_w(X2, x2);   // xk2 = min(x2, X2): x2 carries it when it is the smaller
+      dint[3] = iw * gmax_w(Y2, y2);
+    }
+    const float darea[4] = {-ph, -pw, ph, pw};
+    const float drho[4] = {sx, sy, sx, sy};
+    const float dc2[4] = {-2.f * cw * gmax_w(X1, x1), -2.f * chh * gmax_w(Y1, y1), 2.f * cw * gmax_w(x2, X2),
+                          2.f * chh * gmax_w(y2, Y2)};
+    const float q = pw / ph, dat = 1.f / (1.f + q * q);  // d atan(q) / dq
+    const float dv_dw = -2.f * kv * da * dat / ph, dv_dh = 2.f * kv * da * dat * pw / (ph * ph);
+    const float dv[4] = {-dv_dw, -dv_dh, dv_dw, dv_dh};
+    const float scale = keep * 10.f * w * inv_wsum;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float duni = darea[k] - dint[k];
+      const float diou = (dint[k] * ue - inter * duni) / (ue * ue);
+      const float dL = -diou + (drho[k] * c2 - rho2 * dc2[k]) / (c2 * c2) + alpha * dv[k];
+      elem<T>::st((T*)a.d_box + r * 4 + k, scale * dL * a.cand_scale[r * 4 + k] * e[k]);
+    }
+    // ---- class: cross-entropy over C logits
+    const T* lg = (const T*)a.cls + (long)r * a.C;
+    float m = -INFINITY;
+    for (int c = 0; c < a.C; ++c) m = fmaxf(m, elem<T>::ld(lg + c));
+    float z = 0.f;
+    for (int c = 0; c < a.C; ++c) z += expf(elem<T>::ld(lg + c) - m);
+    const int tc = (int)a.tgt_cls[r];
+    const float lse = m + logf(z);
+    s_cls = w * (lse - elem<T>::ld(lg + tc));
+    const float cs = keep * w * inv_wsum, iz = 1.f / z;
+    T* dl = (T*)a.d_cls + (long)r * a.C;
+    for (int c = 0; c < a.C; ++c) elem<T>::st(dl + c, cs * (expf(elem<T>::ld(lg + c) - m) * iz - (c == tc ? 1.f : 0.f)));
+  }
+  // block sums (fixed order inside the block; blocks are summed in order by the finalize kernel)
+  __shared__ float red[4][4];
+  s_loc = wave_sum(s_loc); s_iou = wave_sum(s_iou); s_box = wave_sum(s_box); s_cls = wave_sum(s_cls);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { red[wv][0] = s_loc; red[wv][1] = s_iou; red[wv][2] = s_box; red[wv][3] = s_cls; }
+  __syncthreads();
+  if (threadIdx.x < 4)
+    a.partial[(long)blockIdx.x * 4 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// losses[5] = total, location, box, class, iou (the last three are 0 when none_matched, as the reference's early-out)
+__global__ __launch_bounds__(256) void od_loss_finalize_kernel(const float* __restrict__ partial, int nblocks,
+                                                               const float* loc_norm, const float* iou_norm,
+                                                               const float* wsum, const bool* none_matched,
+                                                               float* __restrict__ losses) {
+  __shared__ double red[4][4];
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < nblocks; b += 256)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] += (double)partial[(long)b * 4 + k];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    double v = s[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) red[wv][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+    const float loc = (float)(t[0] / (double)*loc_norm), iou = (float)(t[1] / (double)*iou_norm);
+    const float box = (float)(t[2] / (double)*wsum), cls = (float)(t[3] / (double)*wsum);
+    const bool nm = *none_matched;
+    losses[0] = nm ? loc : loc + 10.f * box + cls + iou;
+    losses[1] = loc;
+    losses[2] = nm ? 0.f : box;
+    losses[3] = nm ? 0.f : cls;
+    losses[4] = nm ? 0.f : iou;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -335,6 +484,43 @@ int sihl_iseg_mask_decode(const void* feats, const void* dyn, long dstride, cons
   else if (dtype == SIHL_BF16) { if (ot == 128) SIHL_ISEG(bf16_t, 128); else SIHL_ISEG(bf16_t, 64); }
 #undef SIHL_ISEG
   else return SIHL_EARG;
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+
+// Workspace floats of sihl_od_loss: one row of four partial sums per 256-thread block.
+long sihl_od_loss_ws_bytes(long n_positions, int n_rows) {
+  const long n = n_positions > n_rows ? n_positions : n_rows;
+  return ((n + 255) / 256) * 4L * (long)sizeof(float);
+}
+
+// Detection loss and its gradients in one pass (see od_loss_kernel).  loc / iou: [n_positions] head outputs (dtype),
+// box [n_rows][4], cls [n_rows][C]; targets fp32 (tgt_cls int64); normalisers and none_matched are DEVICE scalars.
+// losses[5] = total, location, box, class, iou; d_* = gradients of the total (same dtype / shape as the head outputs).
+int sihl_od_loss(const void* loc, const void* iou, const void* box, const void* cls, const float* loc_target,
+                 const float* rel_iou, const float* cand_off, const float* cand_scale, const float* tgt_box,
+                 const float* wts, const long* tgt_cls, const float* loc_norm, const float* iou_norm, const float* wsum,
+                 const void* none_matched, long n_positions, int n_rows, int C, void* d_loc, void* d_iou, void* d_box,
+                 void* d_cls, float* losses, int dtype, float* ws, long ws_bytes, hipStream_t stream) {
+  if (!loc || !iou || !box || !cls || !loc_target || !rel_iou || !cand_off || !cand_scale || !tgt_box || !wts ||
+      !tgt_cls || !loc_norm || !iou_norm || !wsum || !none_matched || !d_loc || !d_iou || !d_box || !d_cls || !losses ||
+      !ws || n_positions <= 0 || n_rows <= 0 || C <= 0)
+    return SIHL_EARG;
+  if (ws_bytes < sihl_od_loss_ws_bytes(n_positions, n_rows)) return SIHL_EWS;
+  OdLossArgs a;
+  a.loc = loc; a.iou = iou; a.box = box; a.cls = cls; a.loc_target = loc_target; a.rel_iou = rel_iou;
+  a.cand_off = cand_off; a.cand_scale = cand_scale; a.tgt_box = tgt_box; a.wts = wts; a.tgt_cls = tgt_cls;
+  a.loc_norm = loc_norm; a.iou_norm = iou_norm; a.wsum = wsum; a.none_matched = (const bool*)none_matched;
+  a.d_loc = d_loc; a.d_iou = d_iou; a.d_box = d_box; a.d_cls = d_cls; a.partial = ws;
+  a.N1 = n_positions; a.R = n_rows; a.C = C;
+  const long n = n_positions > n_rows ? n_positions : n_rows;
+  const int blocks = (int)((n + 255) / 256);
+  if (dtype == SIHL_F32) hipLaunchKernelGGL(od_loss_kernel<float>, dim3(blocks), dim3(256), 0, stream, a);
+  else if (dtype == SIHL_BF16) hipLaunchKernelGGL(od_loss_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, a);
+  else return SIHL_EARG;
+  hipLaunchKernelGGL(od_loss_finalize_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws, blocks, loc_norm, iou_norm,
+                     wsum, (const bool*)none_matched, losses);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
 }

@@ -20,6 +20,9 @@ from sihl_amd.heads.mlp import MLP
 from sihl_amd.layers.convblocks import Conv2dNormActivation
 
 
+FUSED_LOSS = True  # test / A-B switch: False = the loss as PyTorch device ops (the formulas of the reference, line by line)
+
+
 class ObjectDetection(nn.Module):
     def __init__(self, in_channels: List[int], num_classes: int, bottom_level: int = 3, top_level: int = 5,
                  num_channels: int = 256, num_layers: int = 4, max_instances: int = 100) -> None:
@@ -150,13 +153,24 @@ class ObjectDetection(nn.Module):
         flat = self._flat_feats(inputs)
         P, C = flat.shape[1], flat.shape[2]
         loc_logits = self.loc_head(flat.view(B * P, C)).reshape(B, P)
-        loc_loss = F.binary_cross_entropy_with_logits(loc_logits.float(), t.loc_target, reduction="none")
-        loc_loss = loc_loss.sum() / t.loc_norm
-        z = torch.zeros_like(loc_loss)
+
+        def location_loss():
+            l = F.binary_cross_entropy_with_logits(loc_logits.float(), t.loc_target, reduction="none")
+            return l.sum() / t.loc_norm
+
         if t.num_gt == 0:  # no ground truth in the whole batch (host-side shapes): reference early-out :165-172
+            loc_loss = location_loss()
+            z = torch.zeros_like(loc_loss)
             return loc_loss, {"location_loss": loc_loss, "box_loss": z, "class_loss": z, "iou_loss": z}
 
         iou_preds = self.iou_head(flat.view(B * P, C)).reshape(B, P)
+        if FUSED_LOSS and flat.is_cuda and t.rel_iou.dtype == torch.float32:
+            # the four loss sums and their gradients in one launch (ops.od_loss / sihl_od_loss) instead of ~240 ATen ones
+            sel = torch.index_select(flat.view(B * P, C), 0, t.rows)
+            out = ops.od_loss(loc_logits, iou_preds, self.box_head(sel), self.cls_head(sel), t)
+            return out[0], {"location_loss": out[1], "box_loss": out[2], "class_loss": out[3], "iou_loss": out[4]}
+        loc_loss = location_loss()
+        z = torch.zeros_like(loc_loss)
         iou_loss = F.mse_loss(iou_preds.float(), t.rel_iou, reduction="none").sum() / t.iou_norm
 
         sel = torch.index_select(flat.view(B * P, C), 0, t.rows)

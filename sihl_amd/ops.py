@@ -982,6 +982,42 @@ def layernorm_act(z, gamma, beta, eps=1e-5, act="silu"):
     return LayerNormActFn.apply(z, gamma, beta, eps, act)
 
 
+# ----------------------------------------------------------------------------- detection loss
+class ODLossFn(torch.autograd.Function):
+    """losses[5] = (total, location, box, class, iou) of ObjectDetection.training_step from the head's four outputs and
+    the matching's target tensors, and - in the same launch - the gradients of the total with respect to those outputs
+    (sihl_od_loss): ~240 small ATen launches of loss arithmetic and its autograd become two."""
+
+    @staticmethod
+    def forward(ctx, loc, iou, box, cls, t):
+        loc, iou, box, cls = (x.detach().contiguous() for x in (loc, iou, box, cls))
+        dev = loc.device
+        n1, R, C = loc.numel(), box.shape[0], cls.shape[1]
+        lib = _C.lib()
+        ws = workspace(lib.sihl_od_loss_ws_bytes(n1, R), dev)
+        d_loc, d_iou, d_box, d_cls = (torch.empty_like(x) for x in (loc, iou, box, cls))
+        losses = torch.empty(5, dtype=torch.float32, device=dev)
+        f32 = lambda v: v.detach().float().contiguous()  # noqa: E731
+        rc = lib.sihl_od_loss(_p(loc), _p(iou), _p(box), _p(cls), _p(f32(t.loc_target)), _p(f32(t.rel_iou)),
+                              _p(f32(t.cand_offsets)), _p(f32(t.cand_scales)), _p(f32(t.tgt_box)), _p(f32(t.wts)),
+                              _p(t.tgt_cls.contiguous()), _p(f32(t.loc_norm)), _p(f32(t.iou_norm)), _p(f32(t.wsum)),
+                              _p(t.none_matched), n1, R, C, _p(d_loc), _p(d_iou), _p(d_box), _p(d_cls), _p(losses),
+                              _dt(loc), _p(ws), ws.numel(), _stream())
+        check(rc, "sihl_od_loss")
+        ctx.save_for_backward(d_loc, d_iou, d_box, d_cls)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        d_loc, d_iou, d_box, d_cls = ctx.saved_tensors
+        g0 = g[0]  # only the total is differentiated; the four components are reported values
+        return d_loc * g0.to(d_loc.dtype), d_iou * g0.to(d_iou.dtype), d_box * g0.to(d_box.dtype), d_cls * g0.to(d_cls.dtype), None
+
+
+def od_loss(loc, iou, box, cls, t):
+    return ODLossFn.apply(loc, iou, box, cls, t)
+
+
 # ----------------------------------------------------------------------------- decode
 def topk_rows(x: Tensor, B: int, P: int, K: int, estride: int = 1):
     vals = torch.empty((B, K), dtype=torch.float32, device=x.device)

@@ -408,3 +408,55 @@ def test_maxpool3x3s2_matches_torch(dtype, shape):
     assert torch.equal(y.detach().permute(0, 3, 1, 2).float().cpu(), ref.detach())
     tol = 1e-6 if dtype == torch.float32 else 2e-2
     _close(xd.grad.permute(0, 3, 1, 2), xr.grad, tol, tol, "maxpool dx")
+
+
+@pytest.mark.parametrize("dtype,rtol,atol", DTYPES)
+def test_od_loss_fused_matches_autograd(dtype, rtol, atol):
+    """sihl_od_loss (the four detection-loss sums + their gradients in one launch) against the same formulas as PyTorch
+    device ops differentiated by autograd (heads/object_detection.py:157-208; CIoU = box_ops.complete_box_iou_loss):
+    overlapping, contained and DISJOINT box pairs (no intersection: the IoU term has no gradient), zero-weight rows,
+    and the none_matched branch."""
+    from types import SimpleNamespace
+
+    from sihl_amd.heads.box_ops import complete_box_iou_loss
+    ops = _ops()
+    g = torch.Generator().manual_seed(7)
+    N1, R, C = 3 * 341, 77, 13
+    for none_matched in (False, True):
+        t = SimpleNamespace()
+        t.loc_target = (torch.rand(N1, generator=g) < 0.05).float().to(DEV)
+        t.rel_iou = (torch.rand(N1, generator=g) * (torch.rand(N1, generator=g) < 0.1)).to(DEV)
+        ctr, wh = torch.rand(R, 2, generator=g) * 0.6 + 0.2, torch.rand(R, 2, generator=g) * 0.3 + 0.05
+        t.tgt_box = torch.cat([ctr - wh / 2, ctr + wh / 2], 1).to(DEV)
+        octr = ctr + (torch.rand(R, 2, generator=g) - 0.5) * 0.2
+        octr[:8] += 0.9  # disjoint pairs
+        t.cand_offsets = torch.cat([octr, octr], 1).to(DEV)
+        t.cand_scales = (torch.tensor([[-1.0, -1.0, 1.0, 1.0]]) * (0.02 + 0.1 * torch.rand(R, 1, generator=g))).to(DEV)
+        t.wts = (torch.rand(R, generator=g) * (torch.rand(R, generator=g) < 0.7)).to(DEV)
+        t.tgt_cls = torch.randint(0, C, (R,), generator=g).to(DEV)
+        t.loc_norm, t.iou_norm, t.wsum = t.loc_target.sum(), t.rel_iou.sum(), t.wts.sum()
+        t.none_matched = torch.tensor(none_matched, device=DEV)
+        heads = [torch.randn(N1, generator=g), torch.randn(N1, generator=g), 0.5 * torch.randn(R, 4, generator=g),
+                 2 * torch.randn(R, C, generator=g)]
+        heads = [h.to(DEV, dtype) for h in heads]
+
+        def reference(loc, iou, box, cls):
+            loc_loss = F.binary_cross_entropy_with_logits(loc.float(), t.loc_target, reduction="none").sum() / t.loc_norm
+            iou_loss = F.mse_loss(iou.float(), t.rel_iou, reduction="none").sum() / t.iou_norm
+            pred = t.cand_offsets + t.cand_scales * box.float().exp()
+            box_loss = (t.wts * complete_box_iou_loss(pred, t.tgt_box)).sum() / t.wsum
+            cls_loss = (t.wts * F.cross_entropy(cls.float(), t.tgt_cls, reduction="none")).sum() / t.wsum
+            z = torch.zeros_like(loc_loss)
+            pick = lambda v: torch.where(t.none_matched, z, v)  # noqa: E731
+            total = torch.where(t.none_matched, loc_loss, loc_loss + 10 * box_loss + cls_loss + iou_loss)
+            return torch.stack([total, loc_loss, pick(box_loss), pick(cls_loss), pick(iou_loss)])
+
+        a = [h.clone().requires_grad_(True) for h in heads]
+        b = [h.clone().requires_grad_(True) for h in heads]
+        ref = reference(*a)
+        (ref[0] * 1.7).backward()
+        got = ops.od_loss(b[0], b[1], b[2], b[3], t)
+        (got[0] * 1.7).backward()
+        _close(got, ref, 2e-5, 2e-5, f"losses (none_matched={none_matched})")
+        for n, x, y in zip(("d_loc", "d_iou", "d_box", "d_cls"), b, a):
+            _close(x.grad, y.grad, max(rtol, 1e-4), max(atol, 1e-5), f"{n} (none_matched={none_matched})")
