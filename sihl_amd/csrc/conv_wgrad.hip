@@ -475,6 +475,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_alltaps_kernel(const WgradPara
     }
 }
 
+// Small weight tensors (fewer than 256 workgroups in the kernel below): a workgroup = 16 weight vectors x 16 split
+// groups - thread (v, g) sums the slabs k = g, g + 16, ... of vector v, the 16 groups are folded through LDS in a fixed
+// order (deterministic).  A 64x64 weight with 1 024 slabs (16 MB to read) then runs on 64 workgroups instead of 4.
+__global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n,
+                                                                 int splits, int accumulate) {
+  __shared__ float4 red[16][17];
+  const int v = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const long i = ((long)blockIdx.x * 16 + v) * 4;  // n % 4 == 0 (caller)
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n)
+    for (int k = g; k < splits; k += 16) {
+      const float4 t = *(const float4*)(ws + (long)k * n + i);
+      a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+    }
+  red[g][v] = a;
+  __syncthreads();
+  if (g == 0 && i < n) {
+    float4 r = red[0][v];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) { const float4 t = red[q][v]; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
+    if (accumulate) {
+      const float4 o = *(const float4*)(dw + i);
+      r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+    }
+    *(float4*)(dw + i) = r;
+  }
+}
+
 // dw[i] (+)= sum_k ws[k][i]: every thread owns 4 consecutive weights (16-byte loads) and keeps four split slabs in
 // flight; the scalar version (one float per thread, one slab at a time) ran at ~1.6 TB/s over up to 64 MB of slabs.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n, int splits,
@@ -679,8 +707,12 @@ int sihl_conv2d_wgrad(const void* in, const void* dout, float* dw, int N, int H,
   else if (dtype == SIHL_BF16) rc = launch<bf16_t>(p, stream);
   else return SIHL_EARG;
   if (rc) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream,
-                     (const float*)ws, dw, n, p.splits, accumulate);
+  if ((n + 1023) / 1024 < 256 && (n & 3) == 0 && p.splits >= 16)
+    hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, stream,
+                       (const float*)ws, dw, n, p.splits, accumulate);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream,
+                       (const float*)ws, dw, n, p.splits, accumulate);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
 }
