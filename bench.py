@@ -332,7 +332,8 @@ def main():
         loss, _ = trainer.step(images, targets)
         if args.sync_steps:
             torch.cuda.synchronize()
-    sync()
+    t_enqueued = time.perf_counter() - t0  # host time to ISSUE the steps (the device is still working): if this is
+    sync()                                 # close to the measured time, the step is host-bound
     dt = time.perf_counter() - t0
     trace("timed steps done")
     final_loss = float(loss)
@@ -451,7 +452,8 @@ def main():
     if rank == 0:
         out = {
             "metric": METRIC, "value": args.batch * world * args.steps / dt, "unit": "images/s",
-            "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": n_warm, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "ranks_seen": ranks_seen, "host_issue_ms_per_step": t_enqueued / args.steps * 1e3,
+            "steps": args.steps, "warmup": n_warm, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "ResNet50 + BiFPN(3-7,256ch,3 layers) + ObjectDetection(80 cls) training step: "

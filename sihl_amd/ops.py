@@ -1009,9 +1009,11 @@ class ODLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        d_loc, d_iou, d_box, d_cls = ctx.saved_tensors
-        g0 = g[0]  # only the total is differentiated; the four components are reported values
-        return d_loc * g0.to(d_loc.dtype), d_iou * g0.to(d_iou.dtype), d_box * g0.to(d_box.dtype), d_cls * g0.to(d_cls.dtype), None
+        grads = list(ctx.saved_tensors)
+        # only the total is differentiated (the four components are reported values): scale the stored gradients of the
+        # total by its upstream gradient, all four tensors in one multi-tensor launch
+        out = torch._foreach_mul(grads, g[0])  # out of place: the saved gradients stay valid for a second backward
+        return out[0], out[1], out[2], out[3], None
 
 
 def od_loss(loc, iou, box, cls, t):

@@ -228,6 +228,7 @@ class Trainer:
         broadcast_parameters(model, group=group)
         self.averager = GradientAverager(list(model.parameters()), group=group, bucket_mb=bucket_mb,
                                          force=force_buckets)
+        self._params = list(model.parameters())  # walked once, not per step (clip_grad_norm_)
         self._graphs: Dict[Any, Any] = {}
         self._seen: Dict[Any, int] = {}
         self.scheduler = self._make_scheduler(scheduler, dict(scheduler_kwargs or {}))
@@ -346,7 +347,7 @@ class Trainer:
         self._backward(loss)
         self.averager.finish()
         if self.grad_clip_norm is not None:
-            torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.grad is not None],
+            torch.nn.utils.clip_grad_norm_([p for p in self._params if p.grad is not None],
                                            self.grad_clip_norm)
         self.optimizer.step()
         if self.prepared is not None:
@@ -364,7 +365,7 @@ class Trainer:
             loss, metrics = self.forward_loss(static_images, static_targets)
             self._backward(loss)
             if self.grad_clip_norm is not None:
-                torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.grad is not None],
+                torch.nn.utils.clip_grad_norm_([p for p in self._params if p.grad is not None],
                                                self.grad_clip_norm)
             self.optimizer.step()
             if self.prepared is not None:
@@ -373,7 +374,8 @@ class Trainer:
         return graph, leaves, loss.detach(), {k: (v.detach() if isinstance(v, Tensor) else v) for k, v in metrics.items()}
 
     def step(self, images: Tensor, targets: List[Any]):
-        self.model.train()
+        if not self.model.training:  # (Module.train() walks every submodule: 2 ms of host time per step when unconditional)
+            self.model.train()
         if not self.use_graph:
             return self._eager_step(images, targets)
         leaves = [images] + _tree_tensors(targets, [])

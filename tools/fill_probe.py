@@ -1,4 +1,5 @@
-"""Developer probe (GPU box): which Python call sites launch the fill / copy kernels of a training step."""
+"""Developer probe (GPU box): which ATen ops launch the small copy / fill kernels of a training step (by op name and
+input shapes; single-stream step so that everything is on one timeline)."""
 import collections
 import os
 import sys
@@ -22,16 +23,19 @@ images, targets = bench.synthetic_batch(32, 512, dev, 0)
 for _ in range(3):
     tr.step(images, targets)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     tr.step(images, targets)
     torch.cuda.synchronize()
 by = collections.Counter()
 for ev in prof.events():
-    n = ev.name
-    if n in ("aten::fill_", "aten::zero_", "aten::copy_", "aten::zeros", "aten::zeros_like", "aten::new_zeros", "aten::clone",
-             "aten::contiguous", "aten::to", "aten::_to_copy"):
-        st = [s for s in (ev.stack or []) if "sihl_amd" in s or "bench.py" in s or "torch/optim" in s or "clip_grad" in s
-              or "autograd" in s]
-        by[(n, tuple(st[:3]))] += 1
-for (n, st), c in by.most_common(40):
-    print(f"{c:5d}  {n:18s}  {' <- '.join(s.split('/')[-1][:70] for s in st)}")
+    if ev.device_type == torch.autograd.DeviceType.CPU and ev.name.startswith("aten::") and ev.cpu_parent is None:
+        kids = sum(1 for k in prof.events() if False)
+    if ev.device_type == torch.autograd.DeviceType.CPU and ev.name in (
+            "aten::copy_", "aten::fill_", "aten::zero_", "aten::add", "aten::add_", "aten::clone", "aten::contiguous",
+            "aten::zeros", "aten::zeros_like", "aten::new_zeros", "aten::_to_copy", "aten::cat", "aten::index_select",
+            "aten::mul", "aten::sum", "aten::select_backward", "aten::slice_backward", "aten::index_add_"):
+        parent = ev.cpu_parent.name if ev.cpu_parent is not None else "-"
+        gp = ev.cpu_parent.cpu_parent.name if ev.cpu_parent is not None and ev.cpu_parent.cpu_parent is not None else "-"
+        by[(ev.name, parent[:40], gp[:40], str(ev.input_shapes)[:80])] += 1
+for (n, par, gp, shp), c in by.most_common(60):
+    print(f"{c:4d}  {n:18s} <- {par:40s} <- {gp:40s} {shp}")
