@@ -231,6 +231,8 @@ def main():
     ap.add_argument("--graph-warmup-stream", default="off", choices=["off", "small", "all"],
                     help="debugging only, with --graph: stream mode of the eager warm-up steps before the capture (the "
                          "round-1 fault needed 'all'; a graph Trainer otherwise never uses a second stream)")
+    ap.add_argument("--pointwise-persistent", action="store_true",
+                    help="A/B: HBM-bound 1x1 convs on the persistent weight-stationary kernel (csrc/conv_pw.hip, opt-in)")
     ap.add_argument("--no-fused-loss", action="store_true",
                     help="A/B: the detection loss as PyTorch device ops instead of the fused sihl_od_loss kernel")
     ap.add_argument("--lean", action="store_true",
@@ -285,6 +287,8 @@ def main():
 
     import types
 
+    if args.pointwise_persistent:
+        _C.lib().sihl_conv2d_pw_enable(1)
     if args.no_fused_loss:
         from sihl_amd.heads import object_detection as _od
         _od.FUSED_LOSS = False

@@ -54,6 +54,7 @@ int sihl_conv2d_force_register_staging(int on);
 /* Tuning hook: pixel-tile size of the LDS-DMA kernel for Cout > 128 (0 = heuristic, 128 or 256). */
 int sihl_conv2d_tile_override(int bm);
 int sihl_conv2d_p8_enable(int on);   /* tuning / test hook: 0 = two-stage 256x256 tile instead of the persistent 8-phase kernel */
+int sihl_conv2d_pw_enable(int mode); /* tuning / test hook: 0 = HBM-bound pointwise layers take the one-tile-per-workgroup kernel, not csrc/conv_pw.hip; 1 = default rule; 2 = every shape the kernel can run */
 int sihl_conv2d_nbuf_override(int n); /* tuning hook: LDS stages of the narrow-tile kernels, 0 = default */
 /* Tuning ablation of the LDS-DMA kernel (results are INVALID when non-zero): 1 = no in-loop DMA, 2 = no ds_read/MFMA. */
 int sihl_conv2d_debug(int mode);

@@ -23,6 +23,7 @@ SIGNATURES = {
     "sihl_conv2d_force_register_staging": (I, [I]),
     "sihl_conv2d_tile_override": (I, [I]),
     "sihl_conv2d_p8_enable": (I, [I]),
+    "sihl_conv2d_pw_enable": (I, [I]),
     "sihl_conv2d_nbuf_override": (I, [I]),
     "sihl_conv2d_debug": (I, [I]),
     "sihl_conv2d_strided_classes_enable": (I, [I]),

@@ -82,16 +82,49 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t
   const bool lean = !has_pre && m0 + BM <= p.M;
   if (lean) {
     // (the post-affine of an inference launch - BatchNorm folded behind the activation - stays: one FMA)
-    auto body = [&](auto post_tag) {
-      constexpr bool POST = decltype(post_tag)::value;
+    // bf16: TWO rows at a time (accumulator registers r, r + 1 are neighbouring rows of one column): packed fp32
+    // add / FMA for the bias, the statistics and the post-affine, one v_cvt_pk_bf16_f32 per pair, the two halves stored
+    // with ds_write_b16 / ds_write_b16_d16_hi - 1.5-2 VALU instructions per output instead of 4-5.  Every VALU
+    // instruction costs a wave 4 cycles and this loop runs 64-128 outputs per lane, so on store-heavy layers it, not
+    // HBM, set the pace (tools/pw_ablate.py).  The statistics are summed as (even rows, odd rows) pairs and folded at the
+    // end: the same fp32 partial sums in another order.
+    auto body = [&](auto post_tag, auto bias_tag) {
+      constexpr bool POST = decltype(post_tag)::value, HASB = decltype(bias_tag)::value;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int cl = wn * WTN + j * 32 + (lane & 31);
         const bool cok = n0 + cl < p.Cout;
-        const float bias = (p.bias && cok) ? p.bias[n0 + cl] : 0.f;
+        const float bias = (HASB && cok) ? p.bias[n0 + cl] : 0.f;
         const float s2 = (POST && cok) ? p.post_scale[n0 + cl] : 1.f;
         const float t2 = (POST && p.post_shift && cok) ? p.post_shift[n0 + cl] : 0.f;
         float ssum = 0.f, ssq = 0.f;
+        if constexpr (sizeof(T) == 2) {
+          typedef float f32x2_t __attribute__((ext_vector_type(2)));
+          typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+          f32x2_t sum2 = {0.f, 0.f}, sq2 = {0.f, 0.f};
+          const f32x2_t b2 = {bias, bias}, s2v = {s2, s2}, t2v = {t2, t2};
+          char* col = epi + (wm * WTM + 4 * half) * EPI_STRIDE + cl * 2;
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              const int row = i * 32 + (r & 3) + 8 * (r >> 2);  // (+ wm*WTM + 4*half in `col`); register r + 1 is row + 1
+              f32x2_t v = {acc[i][j][r], acc[i][j][r + 1]};
+              if (HASB) v += b2;
+              if (STATS == 1) { sum2 += v; sq2 = __builtin_elementwise_fma(v, v, sq2); }
+              if (ACT == SIHL_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+              else if (ACT == SIHL_ACT_SILU) { v.x = v.x / (1.f + expf(-v.x)); v.y = v.y / (1.f + expf(-v.y)); }
+              else if (ACT == SIHL_ACT_SIGMOID) { v.x = 1.f / (1.f + expf(-v.x)); v.y = 1.f / (1.f + expf(-v.y)); }
+              if (STATS == 2) { sum2 += v; sq2 = __builtin_elementwise_fma(v, v, sq2); }
+              if (POST) v = __builtin_elementwise_fma(v, s2v, t2v);
+              const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+              *(unsigned short*)(col + row * EPI_STRIDE) = (unsigned short)pk;
+              *(unsigned short*)(col + (row + 1) * EPI_STRIDE) = (unsigned short)(pk >> 16);
+            }
+          }
+          ssum = sum2.x + sum2.y;
+          ssq = sq2.x + sq2.y;
+        } else {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -107,6 +140,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t
             elem<T>::st((T*)(epi + row * EPI_STRIDE) + cl, v);
           }
         }
+        }
         if (STATS) {
           ssum += __shfl_xor(ssum, 32);
           ssq += __shfl_xor(ssq, 32);
@@ -117,8 +151,8 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t
         }
       }
     };
-    if (has_post) body(std::true_type{});
-    else body(std::false_type{});
+    if (has_post) { if (p.bias) body(std::true_type{}, std::true_type{}); else body(std::true_type{}, std::false_type{}); }
+    else { if (p.bias) body(std::false_type{}, std::true_type{}); else body(std::false_type{}, std::false_type{}); }
   } else
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -458,8 +492,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 // (a stage of MFMAs outlasts a DMA round trip); the narrow tiles of small / thin layers were bound by one DMA
 // latency per 64-deep stage and take 3-4.
 
+// waves per SIMD the tile is tuned for (its workgroups share a CU to hide each other's load -> multiply -> store phases):
+// passed to __launch_bounds__ so that an epilogue change cannot silently cost a resident workgroup (the packed bf16
+// epilogue did: 128x128 went from 160 to 171 registers, 3 -> 2 workgroups per CU)
+template <int BM, int BN> constexpr int conv_min_waves() {
+  return (BM == 128 && BN == 64) ? 5 : (BM == 128 && BN == 128) ? 3 : (BM == 256) ? 2 : 1;
+}
+
 template <typename T, int BM, int BN, int WM, int WN, bool DIL, int NBUF, bool ADD = false>
-__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(const ConvParams p) {
+__global__ __launch_bounds__(WM * WN * 64, (conv_min_waves<BM, BN>())) void conv_igemm_dma_kernel(const ConvParams p) {
   constexpr int NTHREADS = WM * WN * 64;
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int KCE = KCB / (int)sizeof(T);
@@ -606,16 +647,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(const Conv
     // the output store of one workgroup runs under the loads of the next).
     const char* As = smem + wm * WTM * KCB;
     const char* Bs = smem + A_BYTES + wn * WTN * KCB;
-    for (int s = 0; s < nstages; ++s) {
+    for (int s = 0; s < ((SIHL_DBG(p) & 64) ? 0 : nstages); ++s) {
       stage_setup(s, 0);
+      if (!(SIHL_DBG(p) & 1)) {
 #pragma unroll
-      for (int j = 0; j < NA; ++j) issue_a(j);
+        for (int j = 0; j < NA; ++j) issue_a(j);
 #pragma unroll
-      for (int j = 0; j < NBL; ++j) issue_b(j);
+        for (int j = 0; j < NBL; ++j) issue_b(j);
+      }
       wait_vm_keep<0>();
       __syncthreads();
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
+      for (int ks = 0; ks < ((SIHL_DBG(p) & 2) ? 0 : NKS); ++ks) {
         uint4 fa[MT], fb[NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) fa[i] = *(const uint4*)(As + i * 32 * KCB + koff[ks]);
@@ -1027,6 +1070,11 @@ int dispatch(const ConvParams& p, hipStream_t stream) {
     // normalisation runs under the other's loads and multiplies (the thin-K pointwise rule of stages_for)
     return launch_dma<T, 128, 256, 2, 2, 1>(p, stream);
   }
+  if constexpr (sizeof(T) == 2) {
+    // HBM-bound pointwise layers (short contraction into >= 128 channels over many pixels): the persistent
+    // weight-stationary kernel of conv_pw.hip
+    if (dma && g_tile_override == 0 && !g_nbuf && sihl_pw_eligible(p)) return sihl_pw_launch(p, stream);
+  }
   if (!dma) {
     if (p.Cout > 128) return launch_reg<T, 256, 2, 2>(p, stream);
     if (p.Cout > 64) return launch_reg<T, 128, 2, 2>(p, stream);
@@ -1088,6 +1136,10 @@ int sihl_conv2d_debug(int mode) { g_dbg = mode; return 0; }
 
 // Tuning / test hook: 0 = the two-stage 256x256 tile instead of the persistent 8-phase kernel (conv_p8.h).
 int sihl_conv2d_p8_enable(int on) { sihl_p8_set_enabled(on != 0); return 0; }
+
+// Tuning / test hook: 0 = HBM-bound pointwise layers take the one-tile-per-workgroup kernel instead of conv_pw.hip;
+// 1 = default rule; 2 = conv_pw.hip for every shape it can run, however small (tests).
+int sihl_conv2d_pw_enable(int mode) { sihl_pw_set_enabled(mode); return 0; }
 
 // Tuning hook: LDS stages of the narrow-tile LDS-DMA kernels (0 = default, 2..4).
 int sihl_conv2d_nbuf_override(int n) { g_nbuf = n; return 0; }

@@ -50,3 +50,7 @@ struct ConvParams {
 bool sihl_p8_eligible(const ConvParams& p);
 int sihl_p8_launch(const ConvParams& p, hipStream_t stream);
 void sihl_p8_set_enabled(bool on);
+// conv_pw.hip: persistent weight-stationary pointwise kernel (1x1, stride 1, Cin <= 256, bf16)
+bool sihl_pw_eligible(const ConvParams& p);
+int sihl_pw_launch(const ConvParams& p, hipStream_t stream);
+void sihl_pw_set_enabled(int mode);  // 0 off, 1 on, 2 on for every eligible shape (tests)

@@ -26,10 +26,15 @@ __device__ __forceinline__ v4i_t make_rsrc(const void* ptr, unsigned bytes) {
 // main loop therefore waits for the DMA itself (s_waitcnt vmcnt(0) before the barrier that publishes the
 // stage).  M0 (the LDS-DMA destination base) is written in the same statement that reads it; nothing else in
 // these kernels uses M0 (gfx9 ds_* instructions do not).
+// s_nop 3 (with the s_mov: 5 wait states): these kernels spill scalar registers to VGPR lanes (100-600 slots), the
+// compiler may reload the descriptor with v_readlane right in front of this statement, and "VALU writes SGPR -> VMEM
+// reads that SGPR" needs 5 wait states which the hazard recogniser cannot insert for an instruction inside inline asm.
+// (s_nop 0 only covered M0.  Found in conv_pw.hip, where a statistics store ran with a stale descriptor and was
+// dropped; whether a DMA of the older kernels ever issued inside the window depends on what else the CU was doing.)
 __device__ __forceinline__ void dma16(unsigned voff, unsigned lds_dst, v4i_t rsrc) {
   asm volatile(
       "s_mov_b32 m0, %1\n\t"
-      "s_nop 0\n\t"
+      "s_nop 3\n\t"
       "buffer_load_dwordx4 %0, %2, 0 offen lds"
       :
       : "v"(voff), "s"(lds_dst), "s"(rsrc)
