@@ -1,0 +1,4 @@
+// bf16 instantiations of the implicit-GEMM conv kernels (conv_igemm_impl.h).
+#include "conv_igemm_impl.h"
+
+int sihl_conv_dispatch_bf16(const ConvParams& p, hipStream_t stream) { return dispatch<bf16_t>(p, stream); }

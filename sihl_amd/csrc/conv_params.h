@@ -1,4 +1,4 @@
-// Launch parameters shared by the implicit-GEMM conv kernels (conv_igemm.hip, conv_p8.h).
+// Launch parameters shared by the implicit-GEMM conv kernels (conv_igemm_impl.h, conv_p8.h, conv_pw.hip).
 #pragma once
 #include "common.h"
 

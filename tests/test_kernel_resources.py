@@ -2,11 +2,17 @@
 
 An epilogue feature compiled into every instantiation once raised all of them by ~40 VGPRs and silently took one wave
 per SIMD away (-8 % on the benchmark); occupancy is what lets several workgroups share a CU and hide each other's
-load / multiply / store phases, so it is pinned here."""
+load / multiply / store phases, so it is pinned here (and, since round 2, stated to the compiler through __launch_bounds__).
+
+The same compile's assembly is scanned for the two hazards the hardware does not interlock and hipcc cannot see inside
+inline asm (tools/scan_sgpr_hazard.py): a descriptor SGPR reloaded by v_readlane fewer than 5 wait states before an
+inline buffer instruction, and the data registers of a 16-byte inline store overwritten in the next instruction."""
 import os
 import re
 import shutil
 import subprocess
+import sys
+import tempfile
 
 import pytest
 
@@ -15,7 +21,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 # (BM, BN, WM, WN, stages, addend) -> minimum waves per SIMD
 EXPECTED = {
-    (128, 128, 2, 2, 1, 0): 3,   # large grids of 128x128 tiles: 3 workgroups per CU
+    (128, 128, 2, 2, 1, 0): 4,   # large grids of 128x128 tiles: 4 workgroups per CU (37 KB of LDS each)
     (128, 128, 2, 2, 1, 1): 3,   # ... with the residual-gradient addend
     (128, 128, 2, 2, 4, 0): 2,
     (128, 64, 4, 1, 1, 0): 5,
@@ -27,10 +33,16 @@ EXPECTED = {
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_conv_kernel_occupancy():
-    src = os.path.join(ROOT, "sihl_amd", "csrc", "conv_igemm.hip")
-    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", src, "-o", os.devnull,
+    src = os.path.join(ROOT, "sihl_amd", "csrc", "conv_igemm_bf16.hip")  # the bf16 instantiations of conv_igemm_impl.h
+    asm = os.path.join(tempfile.mkdtemp(), "conv_igemm.s")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", src, "-o", asm,
                         "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from scan_sgpr_hazard import scan
+    total, hits = scan(open(asm).read())
+    os.remove(asm)
+    assert total > 100 and not hits, hits[:5]
     found, name = {}, None
     for line in r.stderr.splitlines():
         m = re.search(r"Function Name: (\S+)", line)
@@ -47,3 +59,22 @@ def test_conv_kernel_occupancy():
     for key, want in EXPECTED.items():
         assert key in found, (key, sorted(found))
         assert found[key] >= want, f"conv_igemm_dma_kernel{key}: {found[key]} waves/SIMD, expected >= {want}"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_pointwise_kernel_inline_asm_hazards():
+    """conv_pw.hip issues loads AND stores through inline asm; both hazards were found in it."""
+    src = os.path.join(ROOT, "sihl_amd", "csrc", "conv_pw.hip")
+    asm = os.path.join(tempfile.mkdtemp(), "conv_pw.s")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", src, "-o", asm],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from scan_sgpr_hazard import scan
+    text = open(asm).read()
+    os.remove(asm)
+    total, hits = scan(text)
+    assert total >= 100 and not hits, hits[:5]
+    # the scanner has teeth: strip the padding and the store-data hazard must show
+    stripped = text.replace("\ts_nop 1\n", "\n")
+    assert scan(stripped)[1], "scanner did not flag 16-byte stores whose data register is recycled at once"
