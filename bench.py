@@ -274,6 +274,11 @@ def main():
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the hot path has no CPU fallback)")
+    # stdout carries the ONE JSON line and nothing else: libraries that print to file descriptor 1 (RCCL's version
+    # banner at communicator creation, MIOpen notes) are pointed at stderr for the rest of the run
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     dev_index = 0 if args.same_device else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -499,7 +504,8 @@ def main():
         out["source_stamp"] = source_stamp()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.size)
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if world > 1:
         dist.barrier()
     if dist.is_initialized():
