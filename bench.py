@@ -237,6 +237,8 @@ def main():
     ap.add_argument("--memory-map", default="",
                     help="diagnostic only: write allocator segments + named tensors (tools/graph_fault_map.py) to this "
                          "file right before the timed steps")
+    ap.add_argument("--main-priority", type=int, default=0,
+                    help="A/B: run the step on a user stream of this HIP priority (-1 = high) instead of the default stream")
     ap.add_argument("--pointwise-persistent", action="store_true",
                     help="A/B: HBM-bound 1x1 convs on the persistent weight-stationary kernel (csrc/conv_pw.hip, opt-in)")
     ap.add_argument("--no-fused-loss", action="store_true",
@@ -335,6 +337,10 @@ def main():
         with torch.cuda.stream(extra):
             _dummy = torch.zeros(1024, device=device).add_(1)
         torch.cuda.synchronize()
+    if args.main_priority:
+        torch.cuda.synchronize()
+        _main = torch.cuda.Stream(device=device, priority=args.main_priority)
+        torch.cuda.set_stream(_main)
     for i in range(n_warm):
         trainer.step(images, targets)
         if args.sync_warmup:
@@ -349,6 +355,7 @@ def main():
     if args.unsafe_queue_replays:
         from sihl_amd import ops as _ops
         _ops.side_stream_history = lambda: False
+    allocs0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = trainer.step(images, targets)
@@ -358,7 +365,8 @@ def main():
     sync()                                 # close to the measured time, the step is host-bound
     dt = time.perf_counter() - t0
     trace("timed steps done")
-    final_loss = float(loss)
+    device_allocs = torch.cuda.memory_stats(device).get("num_device_alloc", 0) - allocs0  # hipMalloc calls inside the timed
+    final_loss = float(loss)                                                              # region (each one stalls the host)
     # Per-kernel timing for the roofline object: HIP events around every matrix-core launch, over extra eager steps of
     # the same workload right after the timed region.  Timing events are queue barriers (~3 us of GPU time each, 700
     # per step = 2 ms, 5 % of a step) and a graph replay cannot carry them, so the timed steps themselves run without.
@@ -475,6 +483,7 @@ def main():
         out = {
             "metric": METRIC, "value": args.batch * world * args.steps / dt, "unit": "images/s",
             "n_gpus": world, "ranks_seen": ranks_seen, "host_issue_ms_per_step": t_enqueued / args.steps * 1e3,
+            "device_allocs_in_timed_region": device_allocs,
             "steps": args.steps, "warmup": n_warm, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",

@@ -31,7 +31,9 @@ def _require_gpu(t: Tensor) -> None:
 
 
 def _p(t: Optional[Tensor]):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    # a plain int: the prototypes in _C declare c_void_p, ctypes converts (and None is NULL) - building a c_void_p object
+    # per pointer was ~1 ms of host time per training step (2 200 pointers)
+    return None if t is None else t.data_ptr()
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -40,8 +42,8 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 def _stream():
     """Raw handle of torch's current HIP stream (the fast path avoids building a Stream object per launch)."""
     if _raw_stream is not None:
-        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return _raw_stream(torch.cuda.current_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 _WS = {}
@@ -77,7 +79,7 @@ class deferred_bn_counters:
 
 def workspace(nbytes: int, device) -> Tensor:
     """Grow-only scratch buffer per device (kernels are stream-ordered, so one buffer is shared)."""
-    key = (device.index, _stream().value)
+    key = (device.index, _stream())
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -163,25 +165,20 @@ def side_stream_in_use():
     return _SIDE.stream if _SIDE is not None and _SIDE.dirty else None
 
 
-_RETIRED = []  # (event recorded on the side stream after its last kernel, operands those kernels read)
-
-
-def _purge_retired() -> None:
-    for k in range(len(_RETIRED) - 1, -1, -1):
-        if _RETIRED[k][0].query():
-            del _RETIRED[k]
-
-
 def join_side_stream() -> None:
-    """The current stream waits for every weight gradient queued on the side stream so far.  The operands the side
-    stream read are released only once an event recorded behind its last kernel has COMPLETED (not merely been
-    waited for by the main stream): whichever stream or pool their blocks go to next, no queued reader is left."""
-    _purge_retired()
+    """The current stream waits for every weight gradient queued on the side stream so far, then the operands the side
+    stream read (x, dout, dw) are let go.
+
+    Releasing them at the ENQUEUE of the wait is safe: they are main-stream allocations, the caching allocator never hands
+    a block of one stream's pool to another stream (short of hipFree, which synchronises the device), and every
+    main-stream kernel that could reuse such a block is queued behind this wait - hence behind the side stream's last
+    reader.  (For most of round 2 they were kept until an event behind the side stream's last kernel had COMPLETED.  The
+    host runs one to two steps ahead of the device, so a whole step's activations and gradients - 9 GiB at the benchmark
+    size - stayed alive into the next forward: reserved memory grew 10 -> 20 -> 30 GiB in bursts of 150-250 hipMalloc
+    calls whenever the host got further ahead than before (tools/alloc_probe.py), 15-30 per step inside the timed region,
+    and on a box whose hipMalloc was slow the step went from 31 to 42 ms.)"""
     if _SIDE is not None and _SIDE.dirty:
-        ev = torch.cuda.Event()
-        ev.record(_SIDE.stream)
-        torch.cuda.current_stream().wait_event(ev)
-        _RETIRED.append((ev, _SIDE.holds))
+        torch.cuda.current_stream().wait_stream(_SIDE.stream)
         _SIDE.holds = []
         _SIDE.dirty = False
 
@@ -335,8 +332,6 @@ def conv2d_wgrad_raw(x: Tensor, dout: Tensor, KH: int, KW: int, stride: int, pad
     dw = torch.empty((Cout, KH, KW, Cin), dtype=torch.float32, device=x.device)
     side = _SIDE
     if side is not None and dout.numel() // Cout <= WGRAD_SIDE_MAX_PIXELS[side.mode]:
-        if _RETIRED and not side.dirty:
-            _purge_retired()  # first weight gradient of this backward: the previous step's operands are long done
         nbytes = lib.sihl_conv2d_wgrad_ws_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x), SIDE_WGRAD_TARGET)
         side.stream.wait_stream(torch.cuda.current_stream())  # x and dout are complete on the main stream
         with torch.cuda.stream(side.stream):
