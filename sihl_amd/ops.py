@@ -418,13 +418,25 @@ def norm_act_bwd(s: Tensor, dy: Tensor, mean, rstd, gamma, beta, mode: int, act,
     return dz, dgamma, dbeta
 
 
-def colsum(x: Tensor) -> Tensor:
+def colsum(x: Tensor, off_chain: bool = False) -> Tensor:
+    """Column sums of a (rows, C) tensor.  off_chain: the result is a parameter gradient (a bias): nothing on the backward
+    chain reads it, so inside ``wgrad_side_stream`` it is computed on the side stream like the weight gradients (the side
+    stream ends 0.45 ms before the main stream reaches the join, tools/join_probe.py; 20 such sums per detection step)."""
     C = x.shape[-1]
     rows = x.numel() // C
     lib = _C.lib()
-    ws = workspace(lib.sihl_colsum_ws_bytes(rows, C), x.device)
-    out = torch.empty(C, dtype=torch.float32, device=x.device)
-    rc = lib.sihl_colsum(_p(x), rows, C, _p(out), _dt(x), _p(ws), ws.numel(), _stream())
+    out = torch.empty(C, dtype=torch.float32, device=x.device)  # a main-stream allocation either way (see conv2d_wgrad_raw)
+    side = _SIDE if off_chain else None
+    if side is not None and rows <= WGRAD_SIDE_MAX_PIXELS[side.mode]:
+        side.stream.wait_stream(torch.cuda.current_stream())  # x is complete on the main stream
+        with torch.cuda.stream(side.stream):
+            ws = workspace(lib.sihl_colsum_ws_bytes(rows, C), x.device)
+            rc = lib.sihl_colsum(_p(x), rows, C, _p(out), _dt(x), _p(ws), ws.numel(), _stream())
+        side.holds.append((x, x, out))
+        side.dirty = True
+    else:
+        ws = workspace(lib.sihl_colsum_ws_bytes(rows, C), x.device)
+        rc = lib.sihl_colsum(_p(x), rows, C, _p(out), _dt(x), _p(ws), ws.numel(), _stream())
     check(rc, "sihl_colsum")
     return out
 
@@ -520,7 +532,7 @@ class ConvBlockFn(torch.autograd.Function):
         else:
             x, w, y = ctx.saved_tensors
             dz = affine_act_bwd(y, dy, None, None, "relu") if y is not None else dy
-        dbias = colsum(dz) if ctx.has_bias else None
+        dbias = colsum(dz, off_chain=True) if ctx.has_bias else None
         dw = dx = None
         if ctx.needs_input_grad[1]:
             dw = conv2d_wgrad_raw(x, dz, KH, KW, stride, pad, dil).permute(0, 3, 1, 2)  # (O,I,KH,KW) view
@@ -859,12 +871,12 @@ class LinearFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[1]:  # first: on the side stream it then runs beside the input gradient below
             dw = conv2d_wgrad_raw(x.view(1, 1, rows, Cin), dy.view(1, 1, rows, Cp), 1, 1, 1, 0, 1).view(Cp, Cin)[:Cout]
+        if ctx.has_bias and ctx.needs_input_grad[2]:  # (before dx: the side stream then does not wait for that launch)
+            db = colsum(dy, off_chain=True)[:Cout]
         if ctx.needs_input_grad[0]:
             wt = ctx.wt if ctx.wt is not None else weight_for_dgrad(w.view(Cp, 1, 1, Cin), flip=False)  # [Cin][1][1][Cp]
             dx, _ = conv2d_raw(dy.view(1, 1, rows, Cp), wt)
             dx = dx.view(rows, Cin)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dy)[:Cout]
         return dx, dw, db
 
 
@@ -949,12 +961,12 @@ class LinearLNActFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[1]:  # first: on the side stream it then runs beside the input gradient below
             dw = conv2d_wgrad_raw(x.view(1, 1, rows, Cin), dz.view(1, 1, rows, Cout), 1, 1, 1, 0, 1).view(Cout, Cin)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dz, off_chain=True)
         if ctx.needs_input_grad[0]:
             wt = ctx.wt if ctx.wt is not None else weight_for_dgrad(w.view(Cout, 1, 1, Cin), flip=False)
             dx, _ = conv2d_raw(dz.view(1, 1, rows, Cout), wt)
             dx = dx.view(rows, Cin)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dz)
         return dx, dw, db, dgamma, dbeta, None, None
 
 
