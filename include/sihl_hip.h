@@ -141,6 +141,12 @@ int sihl_affine_add_act(const void* x, const void* res, void* y, long rows, int 
 int sihl_affine_act_bwd(const void* x, const void* dy, void* dx, long rows, int C, const float* scale,
                         const float* shift, int act, int dtype, hipStream_t stream);
 
+/* Batch statistics of an NHWC tensor another kernel produced (the ResNet stem's MIOpen conv): per-channel (sum, sumsq)
+ * partial rows [sihl_bn_stats_rows(...)][2][C] in the layout sihl_bn_finalize reads (torchvision resnet.py stem:
+ * conv1 -> bn1 -> relu, wrapped by src/sihl/torchvision_backbone.py:42-49). */
+int sihl_bn_stats_rows(long rows, int C, int dtype);
+int sihl_bn_stats(const void* x, long rows, int C, float* partials, int n_partials, int dtype, hipStream_t stream);
+
 /* Backward through [activation -> BatchNorm] (mode 0, ConvNormAct: s = act(conv)) or [BatchNorm -> activation]
  * (mode 1, Conv2dNormActivation: s = conv): dz = grad wrt the conv output, dgamma / dbeta fp32 [C].
  * batch_stats != 0 includes the batch-mean / variance terms (training mode). */

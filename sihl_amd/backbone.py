@@ -145,8 +145,17 @@ class _Trunk(nn.Module):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
     def forward(self, x: Tensor, n_taps: int, native: bool = False) -> List[Tensor]:
-        taps = [self.relu(self.bn1(self.conv1(x)))]
-        vec = 8 if taps[0].dtype == torch.bfloat16 else 4
+        z = self.conv1(x)
+        vec = 8 if z.dtype == torch.bfloat16 else 4
+        if native and self.bn1.training and torch.is_grad_enabled() and z.is_cuda and z.dtype in (torch.bfloat16, torch.float32) \
+                and z.shape[1] % vec == 0 and self.bn1.momentum is not None and self.bn1.track_running_stats \
+                and self.bn1.weight.requires_grad and not os.environ.get("SIHL_ATEN_STEM_BN"):  # env: A/B switch
+            # the stem's conv stays MIOpen's (7x7 over 3 channels); its BatchNorm + ReLU, forward and backward, run on
+            # the sihl kernels: statistics + finalize + one normalise pass instead of MIOpen's three BN kernels and an
+            # ATen ReLU, and one reduce + one apply pass backward instead of threshold_backward + two BN kernels
+            taps = [ops.nchw_view(ops.bn_act_train(ops.nhwc(z), self.bn1, "relu"))]
+        else:
+            taps = [self.relu(self.bn1(z))]
         if native and taps[0].dtype in (torch.bfloat16, torch.float32) and taps[0].shape[1] % vec == 0 \
                 and (self.maxpool.kernel_size, self.maxpool.stride, self.maxpool.padding) == (3, 2, 1) \
                 and not os.environ.get("SIHL_ATEN_MAXPOOL"):  # env: A/B switch

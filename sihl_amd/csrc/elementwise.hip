@@ -1589,6 +1589,36 @@ long sihl_norm_act_bwd_ws_bytes(long rows, int C, int dtype) {
 }
 long sihl_colsum_ws_bytes(long rows, int C) { return (long)reduce_blocks(rows) * C * (long)sizeof(float); }
 
+// Per-channel (sum, sumsq) partial rows [n][2][C] of an NHWC tensor some OTHER kernel produced (the MIOpen stem conv of
+// the ResNet trunk), in the layout sihl_bn_finalize reads: the batch statistics of BatchNorm without the conv epilogue.
+// It is the BatchNorm-backward column reduction with s = dy = x, mean 0 and rstd 1: sum g = sum x, sum g * xhat = sum x^2.
+int sihl_bn_stats_rows(long rows, int C, int dtype) {
+  if (rows <= 0 || C <= 0) return 0;
+  return reduce_blocks(rows, row_lanes(C / (dtype == SIHL_BF16 ? 8 : 4)));
+}
+int sihl_bn_stats(const void* x, long rows, int C, float* partials, int n_partials, int dtype, hipStream_t stream) {
+  if (!x || rows <= 0 || C <= 0 || !partials) return SIHL_EARG;
+  const int nrl = row_lanes(C / (dtype == SIHL_BF16 ? 8 : 4));
+  const int nblk = reduce_blocks(rows, nrl);
+  if (n_partials != nblk) return SIHL_EARG;
+  const int rpb = (int)((rows + nblk - 1) / nblk);
+  const void* s = x;
+  const void* dy = x;
+  const float* mean = nullptr;
+  const float* rstd = nullptr;
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  float* ws = partials;
+  DISPATCH_DTYPE(dtype, {
+    constexpr int V = 16 / sizeof(T);
+    if (C % V) return SIHL_EARG;
+    const size_t red_lds = (size_t)nrl * 2 * C * sizeof(float);
+    SIHL_NBR(0, SIHL_ACT_NONE);
+  });
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
 int sihl_norm_act_bwd(const void* s, const void* dy, void* dz, long rows, int C, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, float* dgamma, float* dbeta, int mode, int act,
                       int batch_stats, int dtype, float* ws, long ws_bytes, hipStream_t stream) {

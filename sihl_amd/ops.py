@@ -441,6 +441,43 @@ def colsum(x: Tensor, off_chain: bool = False) -> Tensor:
     return out
 
 
+# ----------------------------------------------------------------------------- BatchNorm + act on a foreign conv's output
+class BNActFn(torch.autograd.Function):
+    """y = act(BatchNorm(s)) in training mode for an NHWC tensor s that another library's conv produced (the ResNet stem:
+    MIOpen's 7x7 / stride 2 conv over 3 input channels): batch statistics by ``sihl_bn_stats``, then the same
+    finalize / normalise / backward kernels as the fused conv block (ConvBlockFn, order "norm_act")."""
+
+    @staticmethod
+    def forward(ctx, s, gamma, beta, running_mean, running_var, eps, momentum, act):
+        sd = s.detach().contiguous()
+        C = sd.shape[-1]
+        rows = sd.numel() // C
+        lib = _C.lib()
+        n = lib.sihl_bn_stats_rows(rows, C, _dt(sd))
+        stats = torch.empty((n, 2, C), dtype=torch.float32, device=sd.device)
+        check(lib.sihl_bn_stats(_p(sd), rows, C, _p(stats), n, _dt(sd), _stream()), "sihl_bn_stats")
+        mean, rstd, scale, shift = bn_finalize(stats, rows, gamma, beta, eps, momentum, running_mean, running_var)
+        y = affine_act(sd, scale, shift, act)
+        ctx.save_for_backward(sd, mean, rstd, gamma.detach(), beta.detach())
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        s, mean, rstd, gamma, beta = ctx.saved_tensors
+        dz, dgamma, dbeta = norm_act_bwd(s, dy.contiguous(), mean, rstd, gamma, beta, 1, ctx.act, True)
+        return (dz if ctx.needs_input_grad[0] else None), dgamma, dbeta, None, None, None, None, None
+
+
+def bn_act_train(s_nhwc: Tensor, bn: torch.nn.BatchNorm2d, act: Optional[str]) -> Tensor:
+    """Training-mode BatchNorm2d (+ activation) of an NHWC tensor through the sihl kernels; updates bn's running
+    statistics and step counter like nn.BatchNorm2d."""
+    if bn.momentum is None or not bn.track_running_stats or not bn.affine:
+        raise NotImplementedError("bn_act_train: affine BatchNorm2d with a fixed momentum and running statistics only")
+    bump_counter(bn.num_batches_tracked)
+    return BNActFn.apply(s_nhwc, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, act)
+
+
 # ----------------------------------------------------------------------------- conv (+norm +act) block
 class ConvBlockFn(torch.autograd.Function):
     """conv -> act -> BN ("act_norm", ConvNormAct), conv -> BN -> act ("norm_act", torchvision's

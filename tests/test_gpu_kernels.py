@@ -534,3 +534,38 @@ def test_pointwise_persistent_kernel_default_rule_full_size():
     # checksum of checksums against fp32 on a slice (the whole product is 34 GFLOP in fp32: a slice keeps the test fast)
     ref = x[5].float().reshape(-1, 64) @ w.float().reshape(256, 64).T
     torch.testing.assert_close(y1[5].float().reshape(-1, 256), ref, rtol=2e-2, atol=2e-2)
+
+
+# ------------------------------------------------------------------ BatchNorm + ReLU behind a foreign conv (the stem)
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("shape", [(4, 64, 64, 64), (3, 37, 29, 16), (2, 128, 128, 64)])
+def test_bn_act_train_matches_batchnorm2d(shape, dtype, tol):
+    """ops.bn_act_train (sihl_bn_stats -> bn_finalize -> affine_act; norm_act_bwd backward) against nn.BatchNorm2d +
+    ReLU in training mode on the same NHWC tensor: output, input gradient, dgamma / dbeta, running statistics, counter."""
+    from sihl_amd import ops
+
+    N, H, W, C = shape
+    g = torch.Generator(device="cuda").manual_seed(C + H)
+    x32 = torch.randn(N, H, W, C, device="cuda", generator=g) * 1.7 + 0.3
+    dy32 = torch.randn(N, H, W, C, device="cuda", generator=g)
+    ref_bn = torch.nn.BatchNorm2d(C).cuda()
+    with torch.no_grad():
+        ref_bn.weight.uniform_(0.5, 1.5)
+        ref_bn.bias.uniform_(-0.5, 0.5)
+    bn = torch.nn.BatchNorm2d(C).cuda()
+    bn.load_state_dict(ref_bn.state_dict())
+    xq = x32.to(dtype)
+    xr = xq.float().permute(0, 3, 1, 2).requires_grad_(True)  # the reference sees the same (rounded) input, in fp32
+    yr = torch.relu(ref_bn(xr))
+    yr.backward(dy32.to(dtype).float().permute(0, 3, 1, 2))
+    xs = xq.clone().requires_grad_(True)
+    ys = ops.bn_act_train(xs, bn, "relu")
+    ys.backward(dy32.to(dtype))
+    a = tol * max(1.0, float(yr.detach().abs().max()))
+    torch.testing.assert_close(ys.float(), yr.permute(0, 2, 3, 1), rtol=tol, atol=a)
+    torch.testing.assert_close(xs.grad.float(), xr.grad.permute(0, 2, 3, 1), rtol=tol, atol=tol * max(1.0, float(xr.grad.abs().max())))
+    torch.testing.assert_close(bn.weight.grad, ref_bn.weight.grad, rtol=tol, atol=tol * float(ref_bn.weight.grad.abs().max()))
+    torch.testing.assert_close(bn.bias.grad, ref_bn.bias.grad, rtol=tol, atol=tol * float(ref_bn.bias.grad.abs().max()))
+    torch.testing.assert_close(bn.running_mean, ref_bn.running_mean, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(bn.running_var, ref_bn.running_var, rtol=1e-4, atol=1e-5)
+    assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked) == 1
