@@ -78,3 +78,38 @@ def test_pointwise_kernel_inline_asm_hazards():
     # the scanner has teeth: strip the padding and the store-data hazard must show
     stripped = text.replace("\ts_nop 1\n", "\n")
     assert scan(stripped)[1], "scanner did not flag 16-byte stores whose data register is recycled at once"
+
+
+def test_hazard_scanner_on_synthetic_isa():
+    """The scanner itself, on hand-written assembly: it must flag a descriptor reloaded by v_readlane right before an
+    inline buffer instruction and a 16-byte store whose data register is overwritten next, and accept the padded forms."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from scan_sgpr_hazard import scan
+
+    bad_sgpr = """_Zkernel_a:
+\tv_readlane_b32 s6, v186, 2
+\tv_readlane_b32 s7, v186, 3
+\t;;#ASMSTART
+\tbuffer_store_dword v0, v1, s[4:7], 0 offen
+\t;;#ASMEND
+"""
+    ok_sgpr = bad_sgpr.replace("\tbuffer_store_dword", "\ts_nop 4\n\tbuffer_store_dword")
+    bad_data = """_Zkernel_b:
+\t;;#ASMSTART
+\ts_nop 4
+\tbuffer_store_dwordx4 v[0:3], v32, s[80:83], 0 offen
+\t;;#ASMEND
+\tv_add_u32_e32 v0, s1, v32
+"""
+    ok_data = bad_data.replace("0 offen\n", "0 offen\n\ts_nop 1\n", 1)
+    dma = """_Zkernel_c:
+\tv_readlane_b32 s11, v248, 14
+\t;;#ASMSTART
+\ts_mov_b32 m0, s40
+\ts_nop 0
+\tbuffer_load_dwordx4 v2, s[8:11], 0 offen lds
+\t;;#ASMEND
+"""
+    assert len(scan(bad_sgpr)[1]) == 1 and not scan(ok_sgpr)[1]
+    assert len(scan(bad_data)[1]) == 1 and not scan(ok_data)[1]
+    assert len(scan(dma)[1]) == 1 and not scan(dma.replace("s_nop 0", "s_nop 3"))[1]
