@@ -217,3 +217,25 @@ def test_multi_gpu_code_path_on_one_rank_matches_plain_step():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_two_stream_step_reaches_allocator_steady_state():
+    """With the host running ahead of the device (no synchronisation between steps) the two-stream eager step must not
+    keep growing its memory: after a few steps the caching allocator stops calling hipMalloc.  (Holding the side stream's
+    operands until an event behind its last kernel had COMPLETED kept a whole step's tensors alive into the next
+    forward: reserved memory doubled and tripled in bursts of hipMalloc calls, each one a host stall.)"""
+    from sihl_amd.train import Trainer
+
+    model = _model()
+    tr = Trainer(model, lr=LR, autocast_dtype=torch.bfloat16, wgrad_stream="all")
+    images, targets = _batch(3, [3, 0, 5, 2, 4, 1, 2, 3])
+    for _ in range(6):
+        tr.step(images, targets)
+    torch.cuda.synchronize()
+    st0 = torch.cuda.memory_stats()
+    for _ in range(12):  # queued back to back: the host is several steps ahead of the device
+        tr.step(images, targets)
+    torch.cuda.synchronize()
+    st1 = torch.cuda.memory_stats()
+    assert st1["num_device_alloc"] - st0["num_device_alloc"] <= 2, (st0["num_device_alloc"], st1["num_device_alloc"])
+    assert st1["reserved_bytes.all.current"] <= st0["reserved_bytes.all.current"] * 1.05 + (64 << 20)
