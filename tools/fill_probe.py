@@ -13,6 +13,9 @@ import bench  # noqa: E402
 import sihl_amd  # noqa: E402
 from sihl_amd.train import Trainer  # noqa: E402
 
+if "nofused" in sys.argv[1:]:
+    from sihl_amd.heads import object_detection as _od
+    _od.FUSED_LOSS = False
 dev = torch.device("cuda", 0)
 ns = types.SimpleNamespace(ResNetBackbone=sihl_amd.ResNetBackbone, BiFPN=sihl_amd.layers.BiFPN,
                            ObjectDetection=sihl_amd.heads.ObjectDetection, SihlModel=sihl_amd.SihlModel)
@@ -37,5 +40,5 @@ for ev in prof.events():
         parent = ev.cpu_parent.name if ev.cpu_parent is not None else "-"
         gp = ev.cpu_parent.cpu_parent.name if ev.cpu_parent is not None and ev.cpu_parent.cpu_parent is not None else "-"
         by[(ev.name, parent[:40], gp[:40], str(ev.input_shapes)[:80])] += 1
-for (n, par, gp, shp), c in by.most_common(60):
+for (n, par, gp, shp), c in by.most_common(400 if "all" in sys.argv[1:] else 60):
     print(f"{c:4d}  {n:18s} <- {par:40s} <- {gp:40s} {shp}")
