@@ -142,8 +142,28 @@ def measured_peaks(device):
 
     t_copy = best(lambda: dst.copy_(src), 10)
     t_gemm = best(lambda: torch.matmul(a, bmat), 10)
-    return {"copy_GBps": 2 * n * 2 / t_copy / 1e9, "gemm_bf16_TFLOPs": 2 * 8192 ** 3 / t_gemm / 1e12,
-            "what": "torch copy_ of 512 MiB (bytes read + written), torch.matmul 8192^3 bf16 (vendor GEMM), random data"}
+    out = {"copy_GBps": 2 * n * 2 / t_copy / 1e9, "gemm_bf16_TFLOPs": 2 * 8192 ** 3 / t_gemm / 1e12,
+           "what": "torch copy_ of 512 MiB (bytes read + written), torch.matmul 8192^3 bf16 (vendor GEMM), random data"}
+    del src, dst, a, bmat
+    # the vendor CONV on the flagship pyramid shape (L3 of the BiFPN: bs 32, 64x64, 256 -> 256, 3x3), channels_last bf16
+    # through torch / MIOpen, next to the sihl kernel on the same tensors: what "a vendor conv reaches on the L3 shape"
+    try:
+        import torch.nn.functional as F
+        from sihl_amd import ops
+        x = torch.randn(32, 256, 64, 64, device=device, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(256, 256, 3, 3, device=device) * 0.02).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        flops = 2.0 * 32 * 64 * 64 * 256 * 256 * 9
+        t_vendor = best(lambda: F.conv2d(x, w, padding=1), 10)
+        xn, wn = x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1)  # the same memory, NHWC / [O][KH][KW][I] views
+        assert xn.is_contiguous() and wn.is_contiguous()
+        t_sihl = best(lambda: ops.conv2d_raw(xn, wn, None, 1, 1, 1), 10)
+        out["l3_conv_vendor_TFLOPs"] = flops / t_vendor / 1e12
+        out["l3_conv_sihl_TFLOPs"] = flops / t_sihl / 1e12
+        out["l3_conv_us"] = {"vendor": t_vendor * 1e6, "sihl": t_sihl * 1e6}
+        out["what"] += "; l3_conv_*: 3x3 256->256 on 32x64x64 (154.6 GFLOP), torch F.conv2d (MIOpen) vs sihl_conv2d_fwd, same tensors"
+    except Exception as e:  # a yardstick must not take the benchmark down
+        out["l3_conv_error"] = repr(e)[:200]
+    return out
 
 
 def north_star_forward(model, device, dtype, batch, size, iters=20):
