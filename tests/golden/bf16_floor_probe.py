@@ -1,4 +1,4 @@
-"""Developer probe (GPU box): bf16 parity of the deep golden cases against the noise floor of bf16 storage.
+"""Test-infrastructure probe (GPU box; lives under tests/ because it runs the oracle): bf16 parity of the deep golden cases against the noise floor of bf16 storage.
 For every floating result of a case: rms-relative deviation from the fp32 oracle (same bf16-rounded operands) of
   floor = the largest deviation over fp32 oracle runs with bf16's rounding error at every module boundary (bf16 storage
           emulated, and three random rounding patterns: tests/golden/util.bf16_floor)
@@ -8,7 +8,7 @@ import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
