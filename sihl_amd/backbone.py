@@ -10,7 +10,8 @@ the same fused conv block the FPN uses, and the block tail is one normalise + ad
 parity-tested against the oracle ResNet in tests/test_gpu_backbone.py.  ``native=False`` runs the trunk on
 PyTorch-ROCm (MIOpen/CK), which SURVEY §8 a2 allows ("not a hand-kernel target").  Measured on the flagship step
 (round 1, bs 32, 512^2, bf16): 689 img/s native vs 666 img/s MIOpen, and native has no ~45 s MIOpen JIT in the first
-iteration.  The 7x7 stem (3 input channels) + max-pool stay on PyTorch-ROCm in both modes.  CPU tensors (BASELINE
+iteration.  The 7x7 stem conv (3 input channels) stays on PyTorch-ROCm in both modes; in native training mode its
+BatchNorm + ReLU and the max-pool run on the sihl kernels (ops.bn_act_train, ops.maxpool3x3s2).  CPU tensors (BASELINE
 config 1, "stock PyTorch plumbing") always run through plain torch ops with the same parameters.
 """
 import os
