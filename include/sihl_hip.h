@@ -155,6 +155,13 @@ int sihl_norm_act_bwd(const void* s, const void* dy, void* dz, long rows, int C,
                       const float* gamma, const float* beta, float* dgamma, float* dbeta, int mode, int act,
                       int batch_stats, int dtype, float* ws, long ws_bytes, hipStream_t stream);
 
+/* Backward of a residual block's tail y = relu(BatchNorm(s) + identity) (torchvision Bottleneck / BasicBlock merge, wrapped
+ * by src/sihl/torchvision_backbone.py): dres = dy * (y > 0) - the identity branch's gradient - and dz = BatchNorm backward
+ * of dres, the ReLU mask applied inside the column reduction.  ws as for sihl_norm_act_bwd. */
+int sihl_norm_add_relu_bwd(const void* s, const void* dy, const void* y, void* dres, void* dz, long rows, int C,
+                           const float* mean, const float* rstd, const float* gamma, const float* beta, float* dgamma,
+                           float* dbeta, int batch_stats, int dtype, float* ws, long ws_bytes, hipStream_t stream);
+
 /* ---- BiFPN fusion nodes, fused with their producer (layers/bifpn.py:10-17,39-53) --------------------------
  * w = softmax(wraw) exactly as FastNormalizedFusion (bifpn.py:16); wraw is the raw nn.Parameter (fp32).
  * fuse_up2 : out[N][H][W][C] = w0 * bilinear_x2(a[N][H/2][W/2][C]) + w1 * b   (Interpolate scale=2,

@@ -52,6 +52,7 @@ SIGNATURES = {
     "sihl_bn_stats": (I, [P, L, I, P, I, I, P]),
     "sihl_norm_act_bwd_ws_bytes": (L, [L, I, I]),
     "sihl_norm_act_bwd": (I, [P, P, P, L, I, P, P, P, P, P, P, I, I, I, I, P, L, P]),
+    "sihl_norm_add_relu_bwd": (I, [P, P, P, P, P, L, I, P, P, P, P, P, P, I, I, P, L, P]),
     "sihl_fuse_up2": (I, [P, P, P, P, I, I, I, I, I, P]),
     "sihl_fuse_up2_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "sihl_nearest_up2_add": (I, [P, P, P, I, I, I, I, I, P]),

@@ -733,11 +733,16 @@ __global__ void fusion_wgrad_kernel(const float* wraw, const float* g, float* dw
 // mode 1: g = dy*act'(xhat*gamma+beta); sums of g and g*xhat   [norm -> act, s = pre-norm tensor]
 // Thread -> (channel vector cv, row lane rl): a block's rows are dealt to nrl = TPB/cvec row lanes, folded
 // through LDS into ONE partial row per block: part[block][2][C].
-template <typename T, int MODE, int ACT>
+// MASK (the tail of a residual block, y = relu(BN(s) + identity)): the incoming gradient is first masked by y > 0 - the
+// gradient of both merge inputs, written to `dres` for the identity branch and for the apply pass - in the SAME pass that
+// folds it into the column sums: one kernel and 4 tensor passes (s, dy, y read; dres written) where a separate ReLU
+// backward + this reduction took 5.
+template <typename T, int MODE, int ACT, bool MASK = false>
 __global__ void norm_bwd_reduce_kernel(const T* __restrict__ s, const T* __restrict__ dy, long rows, int C,
                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                       float* __restrict__ part, int rows_per_block, int nrl) {
+                                       float* __restrict__ part, int rows_per_block, int nrl,
+                                       const T* __restrict__ ymask = nullptr, T* __restrict__ dres = nullptr) {
   constexpr int V = 16 / sizeof(T);
   const int cvec = C / V;
   const long r0 = (long)blockIdx.x * rows_per_block;
@@ -757,6 +762,13 @@ __global__ void norm_bwd_reduce_kernel(const T* __restrict__ s, const T* __restr
       float fs[V], fd[V];
       ldv(s + (r * cvec + cv) * V, fs);
       ldv(dy + (r * cvec + cv) * V, fd);
+      if (MASK) {
+        float fy[V];
+        ldv(ymask + (r * cvec + cv) * V, fy);
+#pragma unroll
+        for (int e = 0; e < V; ++e) fd[e] = fy[e] > 0.f ? fd[e] : 0.f;
+        stv(dres + (r * cvec + cv) * V, fd);
+      }
 #pragma unroll
       for (int e = 0; e < V; ++e) {
         const float xh = (fs[e] - mu[e]) * rs[e];
@@ -1614,6 +1626,41 @@ int sihl_bn_stats(const void* x, long rows, int C, float* partials, int n_partia
     if (C % V) return SIHL_EARG;
     const size_t red_lds = (size_t)nrl * 2 * C * sizeof(float);
     SIHL_NBR(0, SIHL_ACT_NONE);
+  });
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+// Backward of a residual block's tail  y = relu(BN(s) + identity)  (conv -> BatchNorm, no activation of its own, mode 1):
+// dres = dy * (y > 0) (the gradient of the identity branch AND of BN's output), dz = BN backward of dres.  The mask is
+// applied inside the column reduction (norm_bwd_reduce_kernel<.., MASK>), not in a pass of its own.
+int sihl_norm_add_relu_bwd(const void* s, const void* dy, const void* y, void* dres, void* dz, long rows, int C,
+                           const float* mean, const float* rstd, const float* gamma, const float* beta, float* dgamma,
+                           float* dbeta, int batch_stats, int dtype, float* ws, long ws_bytes, hipStream_t stream) {
+  if (!s || !dy || !y || !dres || !dz || rows <= 0 || C <= 0 || !mean || !rstd || !ws) return SIHL_EARG;
+  const int nrl = row_lanes(C / (dtype == SIHL_BF16 ? 8 : 4));
+  const int nblk = reduce_blocks(rows, nrl);
+  if (ws_bytes < sihl_norm_act_bwd_ws_bytes(rows, C, dtype)) return SIHL_EWS;
+  const int rpb = (int)((rows + nblk - 1) / nblk);
+  float* sums = ws + (long)reduce_blocks(rows) * 2 * C;
+  float* s0 = dbeta ? dbeta : sums;
+  float* s1 = dgamma ? dgamma : sums + C;
+  DISPATCH_DTYPE(dtype, {
+    constexpr int V = 16 / sizeof(T);
+    if (C % V) return SIHL_EARG;
+    const size_t red_lds = (size_t)nrl * 2 * C * sizeof(float);
+    hipLaunchKernelGGL((norm_bwd_reduce_kernel<T, 1, SIHL_ACT_NONE, true>), dim3(nblk), dim3(TPB), red_lds, stream,
+                       (const T*)s, (const T*)dy, rows, C, mean, rstd, gamma, beta, ws, rpb, nrl, (const T*)y, (T*)dres);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, stream, (const float*)ws, nblk, 2, C, s0,
+                       s1);
+    const long nvec = rows * (C / V);
+    bool fixed;
+    const int g = grid_fixed(nvec, C / V, &fixed);
+    const void* dy_apply = dres;  // the apply pass reads the masked gradient
+    {
+      const void* dy = dy_apply;
+      SIHL_NBA_F(1, SIHL_ACT_NONE);
+    }
   });
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;

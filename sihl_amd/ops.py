@@ -7,6 +7,7 @@ tensors the reference API exchanges), fp32 or bf16; statistics, weights' gradien
 parameters are fp32.
 """
 import ctypes
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -47,6 +48,7 @@ def _stream():
 
 
 _WS = {}
+_SPLIT_TAIL_BWD = bool(os.environ.get("SIHL_SPLIT_TAIL_BWD"))
 
 # ---- BatchNorm step counters: one multi-tensor add per training step instead of one tiny kernel per layer
 _DEFERRED_COUNTERS = None
@@ -418,6 +420,22 @@ def norm_act_bwd(s: Tensor, dy: Tensor, mean, rstd, gamma, beta, mode: int, act,
     return dz, dgamma, dbeta
 
 
+def norm_add_relu_bwd(s: Tensor, dy: Tensor, y: Tensor, mean, rstd, gamma, beta, batch_stats: bool):
+    """Backward of y = relu(BN(s) + identity): (dres, dz, dgamma, dbeta) with the ReLU mask applied inside the reduction
+    pass (sihl_norm_add_relu_bwd) instead of a pass of its own."""
+    C = s.shape[-1]
+    rows = s.numel() // C
+    lib = _C.lib()
+    ws = workspace(lib.sihl_norm_act_bwd_ws_bytes(rows, C, _dt(s)), s.device)
+    dres, dz = torch.empty_like(s), torch.empty_like(s)
+    dgamma = torch.empty(C, dtype=torch.float32, device=s.device)
+    dbeta = torch.empty_like(dgamma)
+    rc = lib.sihl_norm_add_relu_bwd(_p(s), _p(dy), _p(y), _p(dres), _p(dz), rows, C, _p(mean), _p(rstd), _p(gamma),
+                                    _p(beta), _p(dgamma), _p(dbeta), int(batch_stats), _dt(s), _p(ws), ws.numel(), _stream())
+    check(rc, "sihl_norm_add_relu_bwd")
+    return dres, dz, dgamma, dbeta
+
+
 def colsum(x: Tensor, off_chain: bool = False) -> Tensor:
     """Column sums of a (rows, C) tensor.  off_chain: the result is a parameter gradient (a bias): nothing on the backward
     chain reads it, so inside ``wgrad_side_stream`` it is computed on the side stream like the weight gradients (the side
@@ -556,8 +574,13 @@ class ConvBlockFn(torch.autograd.Function):
         dres = None
         if ctx.kind == "norm" and ctx.has_res:
             x, w, s, mean, rstd, gamma, beta, y = ctx.saved_tensors
-            dres = affine_act_bwd(y, dy, None, None, "relu")  # dy * (y > 0): gradient of both merge inputs
-            dz, dgamma, dbeta = norm_act_bwd(s, dres, mean, rstd, gamma, beta, 1, None, ctx.batch_stats)
+            # dres = dy * (y > 0), the gradient of both merge inputs, and BatchNorm's backward of it: the mask rides in
+            # the reduction pass (7 tensor passes and 3 launches instead of 8 and 4)
+            if _SPLIT_TAIL_BWD:  # env A/B switch: the separate ReLU-backward pass of round 1
+                dres = affine_act_bwd(y, dy, None, None, "relu")
+                dz, dgamma, dbeta = norm_act_bwd(s, dres, mean, rstd, gamma, beta, 1, None, ctx.batch_stats)
+            else:
+                dres, dz, dgamma, dbeta = norm_add_relu_bwd(s, dy, y, mean, rstd, gamma, beta, ctx.batch_stats)
             if ctx.hand_over is not None:
                 ctx.hand_over.tensor, dres = dres, None
         elif ctx.kind == "norm":
