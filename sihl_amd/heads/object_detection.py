@@ -6,6 +6,7 @@ MLPs on K rows -> fused sigmoid / argmax / closed-form-anchor box decode.
 training_step: same laterals + MLPs (matrix-core kernels with hand-written backward); anchor
 matching and the four losses are fp32 device ops, as in the reference's autocast-disabled islands.
 """
+import os
 from functools import partial
 from types import SimpleNamespace
 from typing import Dict, List, Tuple
@@ -65,7 +66,20 @@ class ObjectDetection(nn.Module):
 
     def _flat_feats(self, inputs: List[Tensor]) -> Tensor:
         """(B, P, C) lateral features, positions in level-major, row-major order (reference :102-105)."""
-        feats = [lat.forward_nhwc(ops.nhwc(inputs[l])) for l, lat in zip(self.levels, self.laterals)]
+        xs = [ops.nhwc(inputs[l]) for l in self.levels]
+        if not torch.is_grad_enabled() and not self.training and xs[0].is_cuda and not os.environ.get("SIHL_CAT_LATERALS"):  # env: A/B
+            # inference: every lateral writes its level's rows straight into the flat buffer (image stride P * C)
+            B, C = xs[0].shape[0], self.num_channels
+            sizes = [x.shape[1] * x.shape[2] for x in xs]
+            P = sum(sizes)
+            flat = torch.empty((B, P, C), dtype=xs[0].dtype, device=xs[0].device)
+            off, ok = 0, True
+            for x, lat, n in zip(xs, self.laterals, sizes):
+                ok = ok and lat.forward_nhwc_into(x, flat[:, off:off + n], P * C)
+                off += n
+            if ok:
+                return flat
+        feats = [lat.forward_nhwc(x) for x, lat in zip(xs, self.laterals)]
         B, C = feats[0].shape[0], feats[0].shape[-1]
         return torch.cat([f.reshape(B, -1, C) for f in feats], dim=1)
 

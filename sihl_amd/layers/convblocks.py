@@ -74,6 +74,26 @@ class _ConvBlock(nn.Sequential):
             y = ops.conv_block(x, weight, bias, None, None, None, None, stride=sh, pad=ph, dil=dh, act=self.act)
         return y if y.shape[-1] == cout else y[..., :cout]
 
+    def forward_nhwc_into(self, x: Tensor, out: Tensor, out_image_stride: int) -> bool:
+        """Inference only: write this block's output for image n at ``out`` + n * out_image_stride elements (a slice of a
+        larger buffer).  Returns False - and writes nothing - when the block is not the plain case the one-launch path
+        covers (the caller then uses forward_nhwc)."""
+        conv, bn = self._parts()
+        vec = _vec(x.dtype)
+        (sh, sw), (ph, pw), (dh, dw) = conv.stride, conv.padding, conv.dilation
+        if (self.training or torch.is_grad_enabled() or conv.groups != 1 or conv.padding_mode != "zeros" or sh != sw
+                or ph != pw or dh != dw or x.shape[-1] % vec or conv.weight.shape[0] % vec or not x.is_cuda
+                or any(isinstance(m, (nn.GroupNorm, nn.Softplus, nn.Softmax)) for m in self)
+                or (bn is not None and (not bn.track_running_stats or not bn.affine))):
+            return False
+        if bn is not None:
+            ops.conv_block_into(out, out_image_stride, x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
+                                bn.running_var, stride=sh, pad=ph, dil=dh, act=self.act, order=self.order, eps=bn.eps)
+        else:
+            ops.conv_block_into(out, out_image_stride, x, conv.weight, conv.bias, None, None, None, None, stride=sh, pad=ph,
+                                dil=dh, act=self.act)
+        return True
+
     def forward(self, x: Tensor) -> Tensor:
         return ops.nchw_view(self.forward_nhwc(ops.nhwc(x)))
 

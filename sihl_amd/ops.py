@@ -648,6 +648,24 @@ class GradCarrier:
         self.expect = False  # a producer (hand_over / dx_to) has committed to park a gradient in this backward
 
 
+def conv_block_into(out: Tensor, out_image_stride: int, x_nhwc, weight, bias, gamma, beta, running_mean, running_var, *,
+                    stride=1, pad=0, dil=1, act=None, order="act_norm", eps=1e-5) -> None:
+    """Inference-only conv block (BatchNorm folded into the conv epilogue) that writes image n's output rows at
+    ``out + n * out_image_stride`` elements: per-level laterals land directly in a head's flat (B, P, C) position buffer,
+    no concatenation pass.  No autograd (call it under no_grad with eval-mode statistics)."""
+    xd = x_nhwc.detach()
+    prep = prepared(weight, xd.dtype)
+    w = prep.w if prep is not None else weight_khwc(weight, xd.dtype)
+    if running_mean is None:
+        conv2d_raw(xd, w, bias, stride, pad, dil, act=act, out=out, out_image_stride=out_image_stride)
+        return
+    scale, shift = bn_eval_affine(gamma, beta, running_mean, running_var, eps)
+    if order == "act_norm":
+        conv2d_raw(xd, w, bias, stride, pad, dil, act=act, post=(scale, shift), out=out, out_image_stride=out_image_stride)
+    else:
+        conv2d_raw(xd, w, bias, stride, pad, dil, act=act, pre=(scale, shift), out=out, out_image_stride=out_image_stride)
+
+
 def conv_block(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, *, stride=1, pad=0, dil=1, act=None,
                order="act_norm", training=False, eps=1e-5, momentum=0.1, residual=None, hand_over=None,
                take_over=None, dx_to=None):
