@@ -215,6 +215,21 @@ int sihl_maxpool3x3s2_bwd(const void* dy, const void* idx, void* dx, int N, int 
 int sihl_linear_ln_act(const void* x, const void* w, const float* bias, const float* gamma, const float* beta, float eps,
                        int act, void* z, void* y, float* mean, float* rstd, long rows, int Cin, int Cout, int dtype,
                        hipStream_t stream);
+/* The WHOLE MLP in one launch, inference (heads/object_detection.py:51-61,108-121; SURVEY App. D counts an MLP as one op):
+ * out[rows][out_stride] = Linear_n(act(LN(Linear_{n-1}(... act(LN(Linear_0(x)))...)))) with a 128-row activation tile
+ * resident in LDS across the layers and the weight panels streamed through an LDS ring (csrc/mlp_fused.hip).  bf16 only;
+ * x: rows of Cin elements, x_stride elements apart; w / bias / gamma / beta: HOST arrays of device pointers - nhidden + 1
+ * weights ([C][Cin], [C][C], ..., [Cout][C]; bf16 row-major) and biases (fp32, entries may be NULL), nhidden LayerNorm
+ * scale / shift vectors (fp32).  Cin, C, Cout <= 256; Cin, C multiples of 8; out_stride a multiple of 8, >= Cout (the
+ * padding columns are written as 0).  Same arithmetic as sihl_conv2d_fwd + sihl_layernorm_act per layer, up to the order
+ * of the two row reductions. */
+int sihl_mlp_fwd_supported(long rows, int Cin, int C, int Cout, int nhidden, int act, int dtype);
+int sihl_mlp_fwd(const void* x, long x_stride, long rows, int Cin, int C, int nhidden, const void* const* w,
+                 const float* const* bias, const float* const* gamma, const float* const* beta, float eps, int act,
+                 int Cout, void* out, int out_stride, int dtype, hipStream_t stream);
+int sihl_mlp_stages(int n); /* tuning hook: LDS stages of the weight ring (2 or 3) */
+int sihl_mlp_stamps(void* buf64); /* diagnostic builds (-DSIHL_MLP_STAMPS): 64 x u64 s_memtime marks of workgroup 0 */
+int sihl_mlp_debug(int mode); /* timing ablations, `make TUNING=1` builds only (results invalid when non-zero) */
 int sihl_layernorm_act(const void* z, void* y, long rows, int C, const float* gamma, const float* beta, float eps,
                        int act, float* mean, float* rstd, int dtype, hipStream_t stream);
 int sihl_layernorm_bwd_waves(long rows); /* workgroups = partial rows of the backward (workspace sizing) */

@@ -31,6 +31,11 @@ SIGNATURES = {
     "sihl_od_loss_ws_bytes": (L, [L, I]),
     "sihl_od_loss": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, P, P, P, P, P, I, P, L, P]),
     "sihl_linear_ln_act": (I, [P, P, P, P, P, F, I, P, P, P, P, L, I, I, I, P]),
+    "sihl_mlp_fwd_supported": (I, [L, I, I, I, I, I, I]),
+    "sihl_mlp_fwd": (I, [P, L, L, I, I, I, P, P, P, P, F, I, I, P, I, I, P]),
+    "sihl_mlp_stages": (I, [I]),
+    "sihl_mlp_debug": (I, [I]),
+    "sihl_mlp_stamps": (I, [P]),
     "sihl_conv2d_dgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "sihl_conv2d_ws_bytes": (L, [I, I, I, I, I, I, I, I, I, I]),
     "sihl_conv2d_fwd_ws": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, P, P, P, I, P, L, L, P, L, P]),

@@ -1100,6 +1100,10 @@ int dispatch(const ConvParams& p, hipStream_t stream) {
         return launch_dma<T, 256, 256, 4, 2>(p, stream);
       }
     }
+    if constexpr (sizeof(T) == 2) {  // tuning: 128 pixels x 256 channels on 8 waves (2 x 4), 2 / 3 LDS stages
+      if (g_tile_override == 2562) return launch_dma<T, 128, 256, 2, 4, 2>(p, stream);
+      if (g_tile_override == 2563) return launch_dma<T, 128, 256, 2, 4, 3>(p, stream);
+    }
     if (g_tile_override == 64 || (g_tile_override == 0 && tiles128 * ((p.Cout + 255) / 256) <= 64))
       return launch_n64<T>(p, stream);
     if (g_tile_override == 1280 || (g_tile_override == 0 && tiles128 * ((p.Cout + 255) / 256) <= 256))

@@ -3,6 +3,7 @@ forward runs the HIP linear (matrix-core 1x1) and LayerNorm+SiLU kernels.  Same 
 state_dict keys as the reference's heads (src/sihl/heads/object_detection.py:51-61)."""
 from typing import List
 
+import torch
 from torch import Tensor, nn
 
 from sihl_amd import ops
@@ -11,6 +12,9 @@ from sihl_amd import ops
 FUSE_LINEAR_LN = False  # opt-in: measured SLOWER than the kernel pair (eval head forward, bs 32: 1.35 vs 0.82 ms bf16, 2.88 vs
 # 2.08 ms fp32, profiles/r02_fused_mlp_layer.txt) - the row normalisation in the conv epilogue (two 32-lane shuffle
 # reductions per 16-byte chunk, one workgroup or two per CU) costs more than the LayerNorm kernel's extra pass over HBM
+
+
+FUSE_WHOLE_MLP = True  # test / A-B switch: False = layer by layer (Linear kernel + LayerNorm kernel) in inference too
 
 
 class MLP(nn.Sequential):
@@ -35,6 +39,15 @@ class MLP(nn.Sequential):
         lead = x.shape[:-1]
         h = x.reshape(-1, x.shape[-1])
         mods = list(self)
+        if FUSE_WHOLE_MLP and not torch.is_grad_enabled():
+            # inference: the whole chain in one launch, activations resident in LDS between the layers (ops.mlp_fused)
+            linears = [m for m in mods if isinstance(m, nn.Linear)]
+            norms = [m for m in mods if isinstance(m, nn.LayerNorm)]
+            rest = [m for m in mods if not isinstance(m, (nn.Linear, nn.LayerNorm, nn.Dropout))]
+            act = "silu" if rest and all(isinstance(m, nn.SiLU) for m in rest) else (None if not rest else "?")
+            if act != "?" and len(rest) == len(norms) and ops.mlp_fused_supported(h, linears, norms, act):
+                out = ops.mlp_fused(h, linears, norms, act)
+                return out.reshape(*lead, out.shape[-1])
         i = 0
         while i < len(mods):
             m = mods[i]

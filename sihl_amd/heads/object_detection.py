@@ -22,6 +22,7 @@ from sihl_amd.layers.convblocks import Conv2dNormActivation
 
 
 FUSED_LOSS = True  # test / A-B switch: False = the loss as PyTorch device ops (the formulas of the reference, line by line)
+CAT_LATERALS = bool(os.environ.get("SIHL_CAT_LATERALS"))  # test / A-B switch (read once): True = per-level outputs + torch.cat
 
 
 class ObjectDetection(nn.Module):
@@ -67,7 +68,7 @@ class ObjectDetection(nn.Module):
     def _flat_feats(self, inputs: List[Tensor]) -> Tensor:
         """(B, P, C) lateral features, positions in level-major, row-major order (reference :102-105)."""
         xs = [ops.nhwc(inputs[l]) for l in self.levels]
-        if not torch.is_grad_enabled() and not self.training and xs[0].is_cuda and not os.environ.get("SIHL_CAT_LATERALS"):  # env: A/B
+        if not torch.is_grad_enabled() and not self.training and xs[0].is_cuda and not CAT_LATERALS:
             # inference: every lateral writes its level's rows straight into the flat buffer (image stride P * C)
             B, C = xs[0].shape[0], self.num_channels
             sizes = [x.shape[1] * x.shape[2] for x in xs]

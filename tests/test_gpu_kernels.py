@@ -193,6 +193,62 @@ def test_linear_ln_act_fused_layer(dtype, rtol, atol):
         _close(a, c, 1e-5 if dtype == torch.float32 else 1e-2, 1e-5 if dtype == torch.float32 else 1e-2, "eval fused vs unfused")
 
 
+@pytest.mark.parametrize("stages", [2, 3])
+def test_whole_mlp_one_launch(stages):
+    """torchvision.ops.MLP as the dense heads use it ([Linear -> LayerNorm -> SiLU] x n -> Linear,
+    heads/object_detection.py:51-61) as ONE launch (sihl_mlp_fwd, bf16 inference) against (a) the layer-by-layer kernels -
+    the same arithmetic on the same bf16-rounded intermediates, equal up to the order of the row reductions - and (b) a
+    plain fp32 PyTorch computation with the same rounding points.  Shapes: the detection head's three MLPs (1 / 80 / 4
+    outputs), ragged last tiles, fewer rows than one tile, narrow heads (32 / 64 / 136 channels: partial K-chunks), an
+    input width that differs from the hidden width, no hidden layer at all, a strided row view."""
+    from sihl_amd import _C
+    from sihl_amd.heads import mlp as mlp_mod
+    assert _C.lib().sihl_mlp_stages(stages) == 0
+    g = torch.Generator().manual_seed(11)
+    cases = [(5456 * 3 + 77, 256, 256, 4, 1), (3200, 256, 256, 4, 80), (3200, 256, 256, 4, 4), (100, 32, 32, 4, 6),
+             (1000, 64, 64, 2, 169), (300, 96, 136, 3, 17), (129, 256, 64, 1, 256), (513, 128, 128, 0, 24)]
+    try:
+        for rows, cin, c, nh, cout in cases:
+            m = mlp_mod.MLP(cin, [c] * nh + [cout], norm_layer=torch.nn.LayerNorm, activation_layer=torch.nn.SiLU)
+            with torch.no_grad():
+                for mod in m:
+                    if isinstance(mod, torch.nn.LayerNorm):
+                        mod.weight.copy_(1 + 0.3 * torch.randn(c, generator=g))
+                        mod.bias.copy_(0.3 * torch.randn(c, generator=g))
+                    elif isinstance(mod, torch.nn.Linear):
+                        mod.bias.copy_(torch.randn(mod.bias.shape, generator=g))
+            x = torch.randn(rows, cin, generator=g).bfloat16()
+            # fp32 reference with the GPU path's rounding points: bf16 operands, bf16 pre-norm rows, bf16 layer outputs
+            h = x.float()
+            lin = [mod for mod in m if isinstance(mod, torch.nn.Linear)]
+            lns = [mod for mod in m if isinstance(mod, torch.nn.LayerNorm)]
+            for k, mod in enumerate(lin):
+                h = F.linear(h, mod.weight.detach().bfloat16().float(), mod.bias.detach())
+                if k < len(lns):
+                    h = F.silu(F.layer_norm(h.bfloat16().float(), (c,), lns[k].weight.detach(), lns[k].bias.detach()))
+                h = h.bfloat16().float()
+            md = m.to(DEV).eval()
+            xd = x.to(DEV)
+            with torch.no_grad():
+                mlp_mod.FUSE_WHOLE_MLP = True
+                assert _ops().mlp_fused_supported(xd, [q for q in md if isinstance(q, torch.nn.Linear)],
+                                                  [q for q in md if isinstance(q, torch.nn.LayerNorm)], "silu")
+                one = md(xd)
+                # a strided view of wider rows must give the same result
+                wide = torch.zeros(rows, cin + 8, device=DEV, dtype=torch.bfloat16)
+                wide[:, :cin] = xd
+                one_strided = md(wide[:, :cin])
+                mlp_mod.FUSE_WHOLE_MLP = False
+                layered = md(xd)
+            assert one.shape == (rows, cout) and layered.shape == (rows, cout)
+            assert torch.equal(one, one_strided), f"strided rows {rows}x{cin}"
+            _close(one, layered, 1e-2, 1e-2, f"whole MLP vs layered {rows}x{cin}>{c}x{nh}>{cout}")
+            _close(one, h, 3e-2, 3e-2, f"whole MLP vs torch {rows}x{cin}>{c}x{nh}>{cout}")
+    finally:
+        mlp_mod.FUSE_WHOLE_MLP = True
+        _C.lib().sihl_mlp_stages(3)
+
+
 @pytest.mark.parametrize("dtype,rtol,atol", DTYPES)
 def test_linear_layernorm(dtype, rtol, atol):
     ops = _ops()

@@ -9,7 +9,6 @@ from sihl_amd import ops
 prep = ops.PreparedWeights(model, torch.bfloat16)
 for rnd in range(3):
     for cat in ("", "1"):
-        if cat: os.environ["SIHL_CAT_LATERALS"] = "1"
-        else: os.environ.pop("SIHL_CAT_LATERALS", None)
+        sihl_amd.heads.object_detection.CAT_LATERALS = bool(cat)
         r = bench.north_star_forward(model, dev, torch.bfloat16, 32, 512, iters=40)
         print("cat" if cat else "into-flat", round(r["ms"], 3), flush=True)
