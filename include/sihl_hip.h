@@ -262,6 +262,7 @@ int sihl_od_loss(const void* loc, const void* iou, const void* box, const void* 
  *             boxes = (offsets + scales*exp(box_raw)) * (W,H,W,H) with closed-form cell anchors (:113-121);
  *             level_hw is a HOST array [n_levels][2] of (h, w), bottom level first.
  * od_anchors: the (P,4) offsets / scales tensors of get_offsets_and_scales (:83-97), for the training loss. */
+int sihl_topk_select_enable(int on); /* test hook: 0 = the full LDS bitonic sort instead of the radix select */
 int sihl_topk_rows(const void* x, int B, int P, int K, int estride, float* vals, int* idx, int dtype,
                    hipStream_t stream);
 int sihl_gather_rows(const void* src, const int* idx, void* out, int B, int P, int K, int C, int dtype,

@@ -77,6 +77,7 @@ SIGNATURES = {
     "sihl_layernorm_act_bwd": (I, [P, P, P, L, I, P, P, P, P, I, P, P, I, P, L, P]),
     "sihl_colsum_ws_bytes": (L, [L, I]),
     "sihl_colsum": (I, [P, L, I, P, I, P, L, P]),
+    "sihl_topk_select_enable": (I, [I]),
     "sihl_topk_rows": (I, [P, I, I, I, I, P, P, I, P]),
     "sihl_gather_rows": (I, [P, P, P, I, I, I, I, I, P]),
     "sihl_od_decode": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, I, P]),

@@ -609,6 +609,7 @@ __global__ __launch_bounds__(WM * WN * 64, (conv_min_waves<BM, BN>())) void conv
     n_bbase = lds_base + buf * STAGE + A_BYTES + wave * NBL * 1024;
   };
   auto issue_a = [&](int j) {
+    if ((SIHL_DBG(p) & 128) && n_tap != 0) return;  // tuning ablation: the input tile is fetched for the first tap only
     bool ok = (a_mask[j] & n_tapbit) != 0;
     if (!cin_full) ok = ok && (n_kc * KCE + a_ch[j] < p.Cin);
     unsigned voff;
@@ -621,6 +622,7 @@ __global__ __launch_bounds__(WM * WN * 64, (conv_min_waves<BM, BN>())) void conv
     dma16(ok ? voff : OOB, n_abase + j * 1024, in_rsrc);
   };
   auto issue_b = [&](int j) {
+    if ((SIHL_DBG(p) & 256) && n_tap != 0) return;  // tuning ablation: weights fetched for the first tap only
     unsigned voff = b_off[j] + (unsigned)n_bdelta;
     if (!cin_full) voff = (n_kc * KCE + b_ch[j] < p.Cin) ? voff : OOB;
     dma16(voff, n_bbase + j * 1024, wt_rsrc);
@@ -835,12 +837,16 @@ void launch_add_inplace(const ConvParams& p, hipStream_t stream) {
 }
 
 // Second half of a split-K conv: out = epilogue(sum_s partial[s]) with the same bias / statistics / affine / activation
-// chain as conv_epilogue_body.  Workgroup = one 128-pixel statistics row x 32 output channels.  Dense output only
+// chain as conv_epilogue_body.  Workgroup = 32 * ROWS pixels x 32 output channels, thread = 4 consecutive channels of
+// ROWS consecutive pixels.  ROWS = 4: one 128-pixel statistics row per workgroup (training).  ROWS = 1 (no statistics):
+// four times the workgroups - an L7 level is 512 pixels, and 32 workgroups each walking nine slabs with one load in
+// flight took longer (14 us) than the matrix kernel in front of them.  The slabs of up to four splits are requested
+// together, then added in split order (the sum is the same fp32 chain either way).  Dense output only
 // (out_image_stride == Ho*Wo*Cout).
-template <typename T, int ACT, int STATS>
+template <typename T, int ACT, int STATS, int ROWS>
 __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvParams p) {
-  // thread = (4 consecutive channels, 4 consecutive pixels): all splits x 4 rows of 16-byte loads are in flight at once
-  __shared__ float red[2][32][33];
+  static_assert(STATS == 0 || ROWS == 4, "a statistics row is 128 pixels");
+  __shared__ float red[STATS ? 2 : 1][STATS ? 32 : 1][33];
   const int c4 = threadIdx.x & 7, rl = threadIdx.x >> 3;
   const int co = blockIdx.y * 32 + c4 * 4;
   const bool cok = co < p.Cout;  // Cout % 4 == 0 (vector width), so the 4 channels are valid together
@@ -855,27 +861,34 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvPar
     t2[e] = (has_post && p.post_shift && cok) ? p.post_shift[co + e] : 0.f;
   }
   const long slab = (long)p.M * p.Cout;
-  const int mbase = blockIdx.x * 128 + rl * 4;
-  float v[4][4];
+  const int mbase = blockIdx.x * (32 * ROWS) + rl * ROWS;
+  float v[ROWS][4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < ROWS; ++k)
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[k][e] = 0.f;
   if (cok) {
-    for (int sp = 0; sp < p.splits; ++sp) {
+    for (int sp0 = 0; sp0 < p.splits; sp0 += 4) {
+      float4 t[4][ROWS];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (mbase + k < p.M) {
-          const float4 t = *(const float4*)(p.partial + sp * slab + (long)(mbase + k) * p.Cout + co);
-          v[k][0] += t.x; v[k][1] += t.y; v[k][2] += t.z; v[k][3] += t.w;
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k)
+          t[u][k] = (sp0 + u < p.splits && mbase + k < p.M)
+                        ? *(const float4*)(p.partial + (sp0 + u) * slab + (long)(mbase + k) * p.Cout + co)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) {
+          if (sp0 + u < p.splits) { v[k][0] += t[u][k].x; v[k][1] += t[u][k].y; v[k][2] += t[u][k].z; v[k][3] += t[u][k].w; }
         }
-      }
     }
   }
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
   T* __restrict__ out = (T*)p.out;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < ROWS; ++k) {
     const bool ok = cok && mbase + k < p.M;
     float o[4];
 #pragma unroll
@@ -896,7 +909,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvPar
       for (int e = 0; e < 4; ++e) elem<T>::st(dst + e, o[e]);
     }
   }
-  if (STATS) {
+  if constexpr (STATS != 0) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) { red[0][rl][c4 * 4 + e] = ssum[e]; red[1][rl][c4 * 4 + e] = ssq[e]; }
     __syncthreads();
@@ -912,13 +925,14 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvPar
 
 template <typename T>
 void launch_splitk_epilogue(const ConvParams& p, hipStream_t stream) {
-  const dim3 grid((p.M + 127) / 128, (p.Cout + 31) / 32);
-#define SIHL_SKE(A, S) hipLaunchKernelGGL((conv_splitk_epilogue_kernel<T, A, S>), grid, dim3(256), 0, stream, p)
+  const dim3 grid((p.M + 127) / 128, (p.Cout + 31) / 32), grid1((p.M + 31) / 32, (p.Cout + 31) / 32);
+#define SIHL_SKE(A, S) hipLaunchKernelGGL((conv_splitk_epilogue_kernel<T, A, S, 4>), grid, dim3(256), 0, stream, p)
+#define SIHL_SKE1(A) hipLaunchKernelGGL((conv_splitk_epilogue_kernel<T, A, 0, 1>), grid1, dim3(256), 0, stream, p)
   if (p.stats_mode == 0) {
-    if (p.act == SIHL_ACT_NONE) SIHL_SKE(SIHL_ACT_NONE, 0);
-    else if (p.act == SIHL_ACT_RELU) SIHL_SKE(SIHL_ACT_RELU, 0);
-    else if (p.act == SIHL_ACT_SILU) SIHL_SKE(SIHL_ACT_SILU, 0);
-    else SIHL_SKE(SIHL_ACT_SIGMOID, 0);
+    if (p.act == SIHL_ACT_NONE) SIHL_SKE1(SIHL_ACT_NONE);
+    else if (p.act == SIHL_ACT_RELU) SIHL_SKE1(SIHL_ACT_RELU);
+    else if (p.act == SIHL_ACT_SILU) SIHL_SKE1(SIHL_ACT_SILU);
+    else SIHL_SKE1(SIHL_ACT_SIGMOID);
   } else if (p.stats_mode == 1) {
     SIHL_SKE(SIHL_ACT_NONE, 1);
   } else {
@@ -928,6 +942,7 @@ void launch_splitk_epilogue(const ConvParams& p, hipStream_t stream) {
     else SIHL_SKE(SIHL_ACT_SIGMOID, 2);
   }
 #undef SIHL_SKE
+#undef SIHL_SKE1
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NBUF = 2>

@@ -44,6 +44,112 @@ __global__ __launch_bounds__(1024) void topk_rows_kernel(const T* __restrict__ x
   }
 }
 
+// ---- top-K by radix SELECT (the default): the bitonic network above sorts all P2 = 8192 slots of a 5456-position row
+// through 91 barrier-separated stages (112 us at bs 32) to deliver 100 of them.  Here every position gets a unique
+// composite key - (monotone image of the value) : (0xFFFF - index), so "larger key" is exactly the order of `before` -
+// the K-th largest key is found digit by digit (8 bits per pass: LDS histogram of the positions that still match the
+// prefix, suffix scan by one wave), the K positions at or above it are compacted and ordered by rank counting.  bf16 rows
+// have 16-bit value keys: 4 passes; fp32: 6.  One workgroup of 1024 threads per image, 3 barriers per pass.
+template <typename T> struct TopkKey;
+template <> struct TopkKey<float> {
+  static constexpr int BITS = 48;
+  __device__ static __forceinline__ unsigned long long make(float v, int i) {
+    const unsigned u = __float_as_uint(v);
+    const unsigned k = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)k << 16) | (unsigned)(0xFFFF - i);
+  }
+};
+template <> struct TopkKey<bf16_t> {
+  static constexpr int BITS = 32;
+  __device__ static __forceinline__ unsigned long long make(float v, int i) {
+    const unsigned u = __float_as_uint(v);  // low 16 bits are zero: a bf16 value
+    const unsigned k = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return (unsigned long long)(((k >> 16) << 16) | (unsigned)(0xFFFF - i));
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(1024) void topk_select_kernel(const T* __restrict__ x, int P, int K, int estride,
+                                                           float* __restrict__ vals, int* __restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BITS = TopkKey<T>::BITS;
+  float* v = (float*)smem;                                  // [P] values
+  unsigned long long* cand = (unsigned long long*)(v + ((P + 1) & ~1));  // [K] keys of the selected positions
+  __shared__ unsigned hist[256];
+  __shared__ unsigned long long s_prefix;
+  __shared__ int s_krem, s_ncand;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const T* row = x + (long)blockIdx.x * P * estride;
+  for (int i = tid; i < P; i += 1024) v[i] = elem<T>::ld(row + (long)i * estride);
+  if (tid == 0) { s_prefix = 0ULL; s_krem = K; s_ncand = 0; }
+  __syncthreads();
+  for (int shift = BITS - 8; shift >= 0; shift -= 8) {
+    if (tid < 256) hist[tid] = 0u;
+    __syncthreads();
+    const unsigned long long prefix = s_prefix;
+    for (int i0 = 0; i0 < P; i0 += 1024) {
+      const int i = i0 + tid;
+      const unsigned long long key = i < P ? TopkKey<T>::make(v[i], i) : 0ULL;
+      const bool live = i < P && (shift + 8 >= BITS || (key >> (shift + 8)) == prefix);
+      const unsigned d = (unsigned)(key >> shift) & 255u;
+      // a wave whose live lanes all carry one digit (the sign / exponent byte of a row of similar logits) adds once
+      const unsigned long long m = __ballot(live);
+      if (m) {
+        const unsigned d0 = __builtin_amdgcn_readlane(d, __ffsll((long long)m) - 1);
+        if (__ballot(live && d != d0) == 0ULL) {
+          if (lane == 0) atomicAdd(&hist[d0], (unsigned)__popcll(m));
+        } else if (live) {
+          atomicAdd(&hist[d], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {  // bins 4*lane .. 4*lane + 3; suffix sums from the top bin down
+      const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+      const unsigned own = h0 + h1 + h2 + h3;
+      unsigned above = own;  // inclusive suffix sum over lanes >= this one
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_down(above, o);
+        if (lane + o < 64) above += t;
+      }
+      above -= own;  // positions in bins above this lane's four
+      const unsigned krem = (unsigned)s_krem;
+      // the digit of the K-th key: the highest bin b with (count above b) < krem <= (count above b) + hist[b]
+      unsigned a = above;
+      int found = -1;
+      unsigned found_above = 0;
+      if (a < krem && krem <= a + h3) { found = 3; found_above = a; }
+      a += h3;
+      if (found < 0 && a < krem && krem <= a + h2) { found = 2; found_above = a; }
+      a += h2;
+      if (found < 0 && a < krem && krem <= a + h1) { found = 1; found_above = a; }
+      a += h1;
+      if (found < 0 && a < krem && krem <= a + h0) { found = 0; found_above = a; }
+      if (found >= 0) {
+        s_prefix = (prefix << 8) | (unsigned long long)(4 * lane + found);
+        s_krem = (int)(krem - found_above);
+      }
+    }
+    __syncthreads();
+  }
+  // s_prefix is the K-th largest key (keys are unique): exactly K positions are at or above it
+  const unsigned long long kth = s_prefix;
+  for (int i = tid; i < P; i += 1024) {
+    const unsigned long long key = TopkKey<T>::make(v[i], i);
+    if (key >= kth) cand[atomicAdd(&s_ncand, 1)] = key;
+  }
+  __syncthreads();
+  for (int t = tid; t < K; t += 1024) {
+    const unsigned long long mine = cand[t];
+    int rank = 0;
+    for (int j = 0; j < K; ++j) rank += cand[j] > mine ? 1 : 0;
+    const int i = 0xFFFF - (int)(mine & 0xFFFFULL);
+    vals[(long)blockIdx.x * K + rank] = v[i];
+    idx[(long)blockIdx.x * K + rank] = i;
+  }
+}
+
 // out[b][k][:] = src[b][idx[b][k]][:]
 template <typename T>
 __global__ void gather_rows_kernel(const T* __restrict__ src, const int* __restrict__ idx, T* __restrict__ out, int B,
@@ -385,13 +491,36 @@ __global__ __launch_bounds__(256) void od_loss_finalize_kernel(const float* __re
 
 }  // namespace
 
+static bool g_topk_select = true;
+
 extern "C" {
+
+// Test hook: 0 = the full bitonic sort (kept as the fallback for rows beyond 65535 positions or K > 4096).
+int sihl_topk_select_enable(int on) { g_topk_select = on != 0; return SIHL_OK; }
 
 // x: [B][P] with `estride` elements between consecutive positions (dtype) -> vals fp32 [B][K] (sorted
 // descending), idx int32 [B][K]
 int sihl_topk_rows(const void* x, int B, int P, int K, int estride, float* vals, int* idx, int dtype,
                    hipStream_t stream) {
   if (!x || !vals || !idx || B <= 0 || P <= 0 || K <= 0 || K > P || estride <= 0) return SIHL_EARG;
+  if (g_topk_select && P <= 0xFFFF && K <= 4096 && (size_t)(P + 2) * 4 + (size_t)K * 8 <= 150 * 1024) {
+    const size_t lds_sel = (size_t)((P + 1) & ~1) * 4 + (size_t)K * 8;
+    static bool sel_attr = false;
+    if (!sel_attr) {
+      hipError_t e1 = hipFuncSetAttribute((const void*)topk_select_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      hipError_t e2 = hipFuncSetAttribute((const void*)topk_select_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      if (e1 != hipSuccess) return (int)e1;
+      if (e2 != hipSuccess) return (int)e2;
+      sel_attr = true;
+    }
+    if (dtype == SIHL_F32)
+      hipLaunchKernelGGL(topk_select_kernel<float>, dim3(B), dim3(1024), lds_sel, stream, (const float*)x, P, K, estride, vals, idx);
+    else if (dtype == SIHL_BF16)
+      hipLaunchKernelGGL(topk_select_kernel<bf16_t>, dim3(B), dim3(1024), lds_sel, stream, (const bf16_t*)x, P, K, estride, vals, idx);
+    else return SIHL_EARG;
+    SIHL_CHECK_LAUNCH();
+    return SIHL_OK;
+  }
   int P2 = 1;
   while (P2 < P) P2 <<= 1;
   const size_t lds = (size_t)P2 * 8;

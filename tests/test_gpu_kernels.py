@@ -309,6 +309,58 @@ def test_topk_gather_decode():
     assert torch.equal(idx.cpu().long(), i)
 
 
+def test_topk_radix_select_equals_full_sort():
+    """The radix-select top-K (default) against (a) a stable descending sort on the CPU - value descending, ties by
+    ascending index, the order both kernels promise - and (b) the LDS bitonic sort it replaced, bit for bit: rows with
+    heavy ties (bf16 logits of a freshly initialised head take a few dozen distinct values), all-equal rows, K = 1,
+    K = P, +-inf, a strided single-column view, the full-size pyramid, fp32 rows that differ in the last bit."""
+    from sihl_amd import _C
+    ops = _ops()
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(7)
+
+    def want(x, K):
+        order = torch.sort(x.float(), dim=1, descending=True, stable=True).indices[:, :K]
+        return torch.gather(x.float(), 1, order), order
+
+    cases = []
+    cases.append((torch.randn(32, 5456, generator=g).bfloat16(), 100))                     # the head's shape
+    cases.append(((torch.randn(4, 5456, generator=g) * 0.05 - 5).bfloat16(), 100))          # few distinct values
+    cases.append((torch.full((2, 777), -5.0).bfloat16(), 100))                             # all equal: indices 0..K-1
+    cases.append((torch.randn(3, 341, generator=g), 1))
+    cases.append((torch.randn(3, 341, generator=g), 341))
+    x = torch.randn(2, 1000, generator=g)
+    x[0, 5], x[0, 900], x[1, 17] = float("inf"), float("-inf"), float("inf")
+    cases.append((x, 100))
+    base = torch.full((2, 4096), 1.0)
+    base[:, ::3] = torch.nextafter(torch.tensor(1.0), torch.tensor(2.0))                   # fp32 neighbours
+    cases.append((base, 128))
+    cases.append((torch.randn(2, 16000, generator=g), 300))
+    cases.append((torch.randint(-3, 3, (5, 2000), generator=g).float(), 64))               # signed, zeros, many ties
+    try:
+        for x, K in cases:
+            B, P = x.shape
+            wv, wi = want(x, K)
+            xd = x.to(DEV)
+            lib.sihl_topk_select_enable(1)
+            v1, i1 = ops.topk_rows(xd, B, P, K)
+            lib.sihl_topk_select_enable(0)
+            v0, i0 = ops.topk_rows(xd, B, P, K)
+            assert torch.equal(i1.cpu().long(), wi), f"select vs stable sort {tuple(x.shape)} K={K} {x.dtype}"
+            assert torch.equal(v1.cpu(), wv)
+            assert torch.equal(i1, i0) and torch.equal(v1, v0), f"select vs bitonic {tuple(x.shape)} K={K}"
+        # strided rows: logits in column 0 of an (B*P, 8) buffer
+        x, K = cases[0]
+        B, P = x.shape
+        pad = torch.zeros(B * P, 8, dtype=x.dtype)
+        pad[:, 0] = x.reshape(-1)
+        lib.sihl_topk_select_enable(1)
+        v2, i2 = ops.topk_rows(pad.to(DEV), B, P, K, estride=8)
+        assert torch.equal(i2.cpu().long(), want(x, K)[1])
+    finally:
+        lib.sihl_topk_select_enable(1)
+
+
 def test_prepared_weights_match_per_layer_casts():
     """One-launch operand preparation == the per-layer cast + flip/transpose it replaces, for channels-last and
     plain conv weights and a narrow Linear (rows padded to the vector width); stale copies are not picked up."""
