@@ -250,36 +250,40 @@ __device__ __forceinline__ Lerp up2_src(int dst, int in_size) {
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
 // out = w0 * up2(a) + w1 * b          a: [N][H/2][W/2][C], b/out: [N][H][W][C]
+// One output ROW per blockIdx.y (the row's image, source rows and row weights are wave-uniform: scalar registers),
+// blockIdx.x * TPB + tid = (column, channel vector) of that row, 32-bit index arithmetic.  The earlier form - one flat
+// 64-bit index per vector, split by three runtime divisions - spent ~600 instructions per 16-byte output, and that, not
+// HBM, set its pace (L3: 36 us for 75 MB; rocprofv3 r03_ns_forward).
 template <typename T>
 __global__ void fuse_up2_kernel(const T* __restrict__ a, const T* __restrict__ b, const float* __restrict__ wraw,
                                 T* __restrict__ out, int N, int H, int W, int C) {
   constexpr int V = 16 / sizeof(T);
-  const int cvec = C / V, h2 = H / 2, w2 = W / 2;
-  const long nvec = (long)N * H * W * cvec;
+  const unsigned cvec = C / V, h2 = H / 2, w2 = W / 2;
+  const unsigned xc = blockIdx.x * TPB + threadIdx.x;
+  if (xc >= (unsigned)W * cvec) return;
+  const unsigned x = xc / cvec, cv = xc - x * cvec;
+  const unsigned row = blockIdx.z * 65535u + blockIdx.y;
+  if (row >= (unsigned)N * (unsigned)H) return;
+  const unsigned n = row / (unsigned)H, y = row - n * (unsigned)H;
   float w[3];
   softmax_w(wraw, 2, w);
   if (!b) { w[0] = 1.f; w[1] = 0.f; }
-  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
-    const int cv = (int)(i % cvec);
-    long pix = i / cvec;
-    const int x = (int)(pix % W); pix /= W;
-    const int y = (int)(pix % H);
-    const int n = (int)(pix / H);
-    const Lerp ly = up2_src(y, h2), lx = up2_src(x, w2);
-    const T* an = a + (long)n * h2 * w2 * C + cv * V;
-    float f00[V], f01[V], f10[V], f11[V], o[V];
-    ldv(an + ((long)ly.i0 * w2 + lx.i0) * C, f00);
-    ldv(an + ((long)ly.i0 * w2 + lx.i1) * C, f01);
-    ldv(an + ((long)ly.i1 * w2 + lx.i0) * C, f10);
-    ldv(an + ((long)ly.i1 * w2 + lx.i1) * C, f11);
-    if (b) ldv(b + i * V, o);
+  const Lerp ly = up2_src((int)y, (int)h2), lx = up2_src((int)x, (int)w2);
+  const T* a0 = a + ((long)n * h2 + ly.i0) * w2 * C + cv * V;
+  const T* a1 = a + ((long)n * h2 + ly.i1) * w2 * C + cv * V;
+  const long i = ((long)row * W + x) * C + cv * V;
+  float f00[V], f01[V], f10[V], f11[V], o[V];
+  ldv(a0 + lx.i0 * C, f00);
+  ldv(a0 + lx.i1 * C, f01);
+  ldv(a1 + lx.i0 * C, f10);
+  ldv(a1 + lx.i1 * C, f11);
+  if (b) ldv(b + i, o);
 #pragma unroll
-    for (int e = 0; e < V; ++e) {
-      const float up = ly.l0 * (lx.l0 * f00[e] + lx.l1 * f01[e]) + ly.l1 * (lx.l0 * f10[e] + lx.l1 * f11[e]);
-      o[e] = b ? w[0] * up + w[1] * o[e] : up;
-    }
-    stv(out + i * V, o);
+  for (int e = 0; e < V; ++e) {
+    const float up = ly.l0 * (lx.l0 * f00[e] + lx.l1 * f01[e]) + ly.l1 * (lx.l0 * f10[e] + lx.l1 * f11[e]);
+    o[e] = b ? w[0] * up + w[1] * o[e] : up;
   }
+  stv(out + i, o);
 }
 
 // high-res pass of the adjoint: db = w1*dout, g0 += <dout, up2(a)>, g1 += <dout, b>
@@ -509,48 +513,50 @@ __global__ void resize_bilinear_adjoint_kernel(const T* __restrict__ dout, T* __
 
 // ------------------------------------------------------------------ blur (reflect, [1,2,1]^2/16, stride 2) + fuse
 // out = w0*blur(a) + w1*b + w2*c       a: [N][H][W][C]; b,c,out: [N][Ho][Wo][C]; b==null -> out = blur(a)
+// One output row per blockIdx.y (image and the three reflected source rows: scalar), 32-bit arithmetic - see fuse_up2_kernel.
 template <typename T>
 __global__ void blur_fuse_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c,
                                  const float* __restrict__ wraw, T* __restrict__ out, int N, int H, int W, int Ho,
                                  int Wo, int C) {
   constexpr int V = 16 / sizeof(T);
-  const int cvec = C / V;
-  const long nvec = (long)N * Ho * Wo * cvec;
+  const unsigned cvec = C / V;
+  const unsigned xc = blockIdx.x * TPB + threadIdx.x;
+  if (xc >= (unsigned)Wo * cvec) return;
+  const unsigned ox = xc / cvec, cv = xc - ox * cvec;
+  const unsigned row = blockIdx.z * 65535u + blockIdx.y;
+  if (row >= (unsigned)N * (unsigned)Ho) return;
+  const unsigned n = row / (unsigned)Ho, oy = row - n * (unsigned)Ho;
   float w[3];
   softmax_w(b ? wraw : nullptr, 3, w);
   const float k1[3] = {0.25f, 0.5f, 0.25f};
-  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
-    const int cv = (int)(i % cvec);
-    long pix = i / cvec;
-    const int ox = (int)(pix % Wo); pix /= Wo;
-    const int oy = (int)(pix % Ho);
-    const int n = (int)(pix / Ho);
-    const T* an = a + (long)n * H * W * C + cv * V;
-    float acc[V];
+  const T* an = a + (long)n * H * W * C + cv * V;
+  int xs[3];
 #pragma unroll
-    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+  for (int dx = 0; dx < 3; ++dx) xs[dx] = reflect1(2 * (int)ox + dx - 1, W) * C;
+  float acc[V];
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      const int y = reflect1(2 * oy + dy - 1, H);
+  for (int e = 0; e < V; ++e) acc[e] = 0.f;
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int x = reflect1(2 * ox + dx - 1, W);
-        float f[V];
-        ldv(an + ((long)y * W + x) * C, f);
-        const float k = k1[dy] * k1[dx];
+  for (int dy = 0; dy < 3; ++dy) {
+    const T* ar = an + (long)reflect1(2 * (int)oy + dy - 1, H) * W * C;
 #pragma unroll
-        for (int e = 0; e < V; ++e) acc[e] += k * f[e];
-      }
+    for (int dx = 0; dx < 3; ++dx) {
+      float f[V];
+      ldv(ar + xs[dx], f);
+      const float k = k1[dy] * k1[dx];
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] += k * f[e];
     }
-    if (b) {
-      float fb[V], fc[V];
-      ldv(b + i * V, fb);
-      ldv(c + i * V, fc);
-#pragma unroll
-      for (int e = 0; e < V; ++e) acc[e] = w[0] * acc[e] + w[1] * fb[e] + w[2] * fc[e];
-    }
-    stv(out + i * V, acc);
   }
+  const long i = ((long)row * Wo + ox) * C + cv * V;
+  if (b) {
+    float fb[V], fc[V];
+    ldv(b + i, fb);
+    ldv(c + i, fc);
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = w[0] * acc[e] + w[1] * fb[e] + w[2] * fc[e];
+  }
+  stv(out + i, acc);
 }
 
 // low-res pass of the adjoint: db = w1*dout, dc = w2*dout, g += <dout, {blur(a), b, c}>
@@ -1381,7 +1387,9 @@ int sihl_fuse_up2(const void* a, const void* b, const float* wraw, void* out, in
   DISPATCH_DTYPE(dtype, {
     constexpr int V = 16 / sizeof(T);
     if (C % V) return SIHL_EARG;
-    hipLaunchKernelGGL(fuse_up2_kernel<T>, dim3(grid_for((long)N * H * W * (C / V))), dim3(TPB), 0, stream,
+    const long rows = (long)N * H;  // grid.(y, z) = output rows
+    if (rows > 65535L * 65535L || (long)W * C >= (1L << 31)) return SIHL_EARG;
+    hipLaunchKernelGGL(fuse_up2_kernel<T>, dim3((W * (C / V) + TPB - 1) / TPB, (unsigned)(rows < 65535 ? rows : 65535), (unsigned)((rows + 65534) / 65535)), dim3(TPB), 0, stream,
                        (const T*)a, (const T*)b, wraw, (T*)out, N, H, W, C);
   });
   SIHL_CHECK_LAUNCH();
@@ -1552,7 +1560,9 @@ int sihl_blur_fuse(const void* a, const void* b, const void* c, const float* wra
   DISPATCH_DTYPE(dtype, {
     constexpr int V = 16 / sizeof(T);
     if (C % V) return SIHL_EARG;
-    hipLaunchKernelGGL(blur_fuse_kernel<T>, dim3(grid_for((long)N * Ho * Wo * (C / V))), dim3(TPB), 0, stream,
+    const long rows = (long)N * Ho;  // grid.(y, z) = output rows
+    if (rows > 65535L * 65535L || (long)W * C >= (1L << 31)) return SIHL_EARG;
+    hipLaunchKernelGGL(blur_fuse_kernel<T>, dim3((Wo * (C / V) + TPB - 1) / TPB, (unsigned)(rows < 65535 ? rows : 65535), (unsigned)((rows + 65534) / 65535)), dim3(TPB), 0, stream,
                        (const T*)a, (const T*)b, (const T*)c, wraw, (T*)out, N, H, W, Ho, Wo, C);
   });
   SIHL_CHECK_LAUNCH();

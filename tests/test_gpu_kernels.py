@@ -148,6 +148,44 @@ def test_fuse_up2_and_blur(dtype, rtol, atol):
 
 
 @pytest.mark.parametrize("dtype,rtol,atol", DTYPES)
+def test_fusion_nodes_borders_and_odd_sizes(dtype, rtol, atol):
+    """Forward of the two BiFPN fusion nodes (layers/bifpn.py:39-53: sihl_fuse_up2 / sihl_blur_fuse, one output row per
+    blockIdx.y) against PyTorch on shapes whose every pixel is a border (1 x 1, 2 x 2), odd sizes (odd output heights and
+    widths of the blur, reflection on both sides), rows wider than one workgroup, and without fusion inputs (plain
+    upsample / plain blur)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    for (N, C, h, w) in [(2, 32, 1, 1), (1, 64, 2, 3), (2, 32, 5, 11), (1, 256, 16, 40), (3, 32, 9, 8)]:
+        a = torch.randn(N, h, w, C, generator=g).to(dtype)
+        b = torch.randn(N, 2 * h, 2 * w, C, generator=g).to(dtype)
+        wr = torch.randn(2, generator=g)
+        with torch.no_grad():
+            out = ops.fuse_up2(a.to(DEV), b.to(DEV), wr.to(DEV))
+            plain = ops.up2(a.to(DEV))
+        up = F.interpolate(a.float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear")
+        sm = wr.softmax(0)
+        _close(out.permute(0, 3, 1, 2), sm[0] * up + sm[1] * b.float().permute(0, 3, 1, 2), rtol, atol, f"up2 {N}x{h}x{w}x{C}")
+        _close(plain.permute(0, 3, 1, 2), up, rtol, atol, f"plain up2 {N}x{h}x{w}x{C}")
+    k = torch.tensor([0.25, 0.5, 0.25])
+    k2 = torch.outer(k, k)
+    for (N, C, H, W) in [(2, 32, 2, 2), (1, 64, 3, 3), (2, 32, 7, 9), (1, 256, 32, 80), (2, 32, 10, 17), (1, 32, 5, 2)]:
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        a = torch.randn(N, H, W, C, generator=g).to(dtype)
+        b = torch.randn(N, Ho, Wo, C, generator=g).to(dtype)
+        c = torch.randn(N, Ho, Wo, C, generator=g).to(dtype)
+        wr = torch.randn(3, generator=g)
+        with torch.no_grad():
+            out = ops.blur_fuse(a.to(DEV), b.to(DEV), c.to(DEV), wr.to(DEV))
+            plain = ops.blur_fuse(a.to(DEV))
+        an = a.float().permute(0, 3, 1, 2)
+        blur = F.conv2d(F.pad(an, [1, 1, 1, 1], mode="reflect"), k2[None, None].repeat(C, 1, 1, 1), stride=2, groups=C)
+        sm = wr.softmax(0)
+        ref = sm[0] * blur + sm[1] * b.float().permute(0, 3, 1, 2) + sm[2] * c.float().permute(0, 3, 1, 2)
+        _close(out.permute(0, 3, 1, 2), ref, rtol, atol, f"blur {N}x{H}x{W}x{C}")
+        _close(plain.permute(0, 3, 1, 2), blur, rtol, atol, f"plain blur {N}x{H}x{W}x{C}")
+
+
+@pytest.mark.parametrize("dtype,rtol,atol", DTYPES)
 def test_linear_ln_act_fused_layer(dtype, rtol, atol):
     """One MLP layer (Linear -> LayerNorm -> SiLU, heads/object_detection.py:51-61) as ONE launch against (a) the
     unfused kernel pair - the same arithmetic on the same stored values: equal to summation-order rounding - and (b) a
