@@ -227,6 +227,18 @@ int sihl_mlp_fwd_supported(long rows, int Cin, int C, int Cout, int nhidden, int
 int sihl_mlp_fwd(const void* x, long x_stride, long rows, int Cin, int C, int nhidden, const void* const* w,
                  const float* const* bias, const float* const* gamma, const float* const* beta, float eps, int act,
                  int Cout, void* out, int out_stride, int dtype, hipStream_t stream);
+/* The same MLP with the activations in REGISTERS (csrc/mlp_rows.hip): a wave owns 32 rows and all channels of them, the
+ * accumulators of a layer are normalised, activated and packed in place into the next layer's matrix operand; LDS holds
+ * only the weight ring, two workgroups share a CU.  As sihl_mlp_fwd, except: nhidden >= 1, C == 256, and w[l]
+ * for l >= 1 must be in the K order sihl_mlp_permute_k produces (inside each group of 16 input channels
+ * [0-3, 8-11, 4-7, 12-15] - the order in which a lane's accumulators hold a row's channels); w[0] is plain. */
+int sihl_mlp_rows_supported(long rows, int Cin, int C, int Cout, int nhidden, int act, int dtype);
+int sihl_mlp_rows_delay(int n); /* tuning hook: start delay of alternate workgroups, x 4096 cycles */
+int sihl_mlp_rows_debug(int mode); /* timing ablations, `make TUNING=1` builds only (results invalid when non-zero) */
+int sihl_mlp_permute_k(const void* w_in, void* w_out, long Cout, int K, hipStream_t stream);
+int sihl_mlp_rows_fwd(const void* x, long x_stride, long rows, int Cin, int C, int nhidden, const void* const* w,
+                      const float* const* bias, const float* const* gamma, const float* const* beta, float eps, int act,
+                      int Cout, void* out, int out_stride, int dtype, hipStream_t stream);
 int sihl_mlp_stages(int n); /* tuning hook: LDS stages of the weight ring (2 or 3) */
 int sihl_mlp_stamps(void* buf64); /* diagnostic builds (-DSIHL_MLP_STAMPS): 64 x u64 s_memtime marks of workgroup 0 */
 int sihl_mlp_debug(int mode); /* timing ablations, `make TUNING=1` builds only (results invalid when non-zero) */

@@ -1073,15 +1073,19 @@ class LinearLNActFn(torch.autograd.Function):
         return dx, dw, db, dgamma, dbeta, None, None
 
 
+MLP_KERNEL = os.environ.get("SIHL_MLP_KERNEL", "rows")  # A/B switch: "rows" = activations in registers (mlp_rows.hip),
+# "tile" = the 128-row LDS tile of mlp_fused.hip
+
+
 class _MLPPlan:
     """Pointer tables of one MLP for sihl_mlp_fwd, rebuilt when a parameter (or its prepared bf16 copy) moved or changed."""
-    __slots__ = ("key", "w", "bias", "gamma", "beta", "keep", "dims")
+    __slots__ = ("key", "w", "w_rows", "bias", "gamma", "beta", "keep", "dims")
 
 
 def _mlp_plan(linears, norms, dtype):
     key = tuple((m.weight.data_ptr(), m.weight._version, getattr(getattr(m.weight, "_sihl_prepared", None), "version", None),
                  0 if m.bias is None else m.bias.data_ptr()) for m in linears) + \
-        tuple((n.weight.data_ptr(), n.bias.data_ptr()) for n in norms)
+        tuple((n.weight.data_ptr(), n.bias.data_ptr()) for n in norms) + (MLP_KERNEL,)
     plan = getattr(linears[0], "_sihl_mlp_plan", None)
     if plan is not None and plan.key == key:
         return plan
@@ -1097,6 +1101,17 @@ def _mlp_plan(linears, norms, dtype):
     plan.bias = (ctypes.c_void_p * n)(*[None if m.bias is None else m.bias.data_ptr() for m in linears])
     plan.gamma = (ctypes.c_void_p * max(1, len(norms)))(*[x.weight.data_ptr() for x in norms])
     plan.beta = (ctypes.c_void_p * max(1, len(norms)))(*[x.bias.data_ptr() for x in norms])
+    plan.w_rows = None
+    if MLP_KERNEL == "rows" and len(linears) > 1 and all(w.shape[1] % 16 == 0 for w in keep[1:]):
+        # sihl_mlp_rows_fwd keeps a row's activations in the accumulator registers' channel order: the weights of the layers
+        # behind the first are read with that K order (one permuted copy per weight version, made here)
+        rows_w = [keep[0]]
+        for w in keep[1:]:
+            wp = torch.empty_like(w)
+            check(_C.lib().sihl_mlp_permute_k(_p(w), _p(wp), w.shape[0], w.shape[1], _stream()), "sihl_mlp_permute_k")
+            rows_w.append(wp)
+        keep = keep + rows_w
+        plan.w_rows = (ctypes.c_void_p * n)(*[w.data_ptr() for w in rows_w])
     plan.keep, plan.key = keep, key
     if prepared(linears[0].weight, dtype) is not None or not torch.is_grad_enabled():
         linears[0]._sihl_mlp_plan = plan  # (casts made on the fly are cached too: the key holds the master weight's version)
@@ -1134,6 +1149,12 @@ def mlp_fused(x: Tensor, linears, norms, act: Optional[str]) -> Tensor:
     plan = _mlp_plan(linears, norms, x.dtype)
     Cp = (Cout + 7) // 8 * 8
     out = torch.empty((rows, Cp), dtype=x.dtype, device=x.device)
+    lib = _C.lib()
+    if plan.w_rows is not None and lib.sihl_mlp_rows_supported(rows, Cin, C, Cout, len(norms), ACT[act], BF16):
+        rc = lib.sihl_mlp_rows_fwd(_p(x), x.stride(0), rows, Cin, C, len(norms), plan.w_rows, plan.bias, plan.gamma,
+                                   plan.beta, norms[0].eps, ACT[act], Cout, _p(out), Cp, BF16, _stream())
+        check(rc, "sihl_mlp_rows_fwd")
+        return out if Cp == Cout else out[:, :Cout]
     rc = _C.lib().sihl_mlp_fwd(_p(x), x.stride(0), rows, Cin, C, len(norms), plan.w, plan.bias, plan.gamma, plan.beta,
                                norms[0].eps if norms else 0.0, ACT[act], Cout, _p(out), Cp, BF16, _stream())
     check(rc, "sihl_mlp_fwd")

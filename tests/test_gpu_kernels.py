@@ -231,7 +231,7 @@ def test_linear_ln_act_fused_layer(dtype, rtol, atol):
         _close(a, c, 1e-5 if dtype == torch.float32 else 1e-2, 1e-5 if dtype == torch.float32 else 1e-2, "eval fused vs unfused")
 
 
-@pytest.mark.parametrize("stages", [2, 3])
+@pytest.mark.parametrize("stages", [2, 3, "rows"])
 def test_whole_mlp_one_launch(stages):
     """torchvision.ops.MLP as the dense heads use it ([Linear -> LayerNorm -> SiLU] x n -> Linear,
     heads/object_detection.py:51-61) as ONE launch (sihl_mlp_fwd, bf16 inference) against (a) the layer-by-layer kernels -
@@ -241,10 +241,21 @@ def test_whole_mlp_one_launch(stages):
     input width that differs from the hidden width, no hidden layer at all, a strided row view."""
     from sihl_amd import _C
     from sihl_amd.heads import mlp as mlp_mod
-    assert _C.lib().sihl_mlp_stages(stages) == 0
     g = torch.Generator().manual_seed(11)
     cases = [(5456 * 3 + 77, 256, 256, 4, 1), (3200, 256, 256, 4, 80), (3200, 256, 256, 4, 4), (100, 32, 32, 4, 6),
              (1000, 64, 64, 2, 169), (300, 96, 136, 3, 17), (129, 256, 64, 1, 256), (513, 128, 128, 0, 24)]
+    ops_mod = _ops()
+    kernel_before = ops_mod.MLP_KERNEL
+    if stages == "rows":
+        # the register-resident kernel (sihl_mlp_rows_fwd: hidden width 256): the head's three MLPs, an input narrower than
+        # the hidden width with a partial K-chunk, one and eight hidden layers, every last-layer block count (1 / 3 / 8)
+        ops_mod.MLP_KERNEL = "rows"
+        cases = cases[:3] + [(1000, 72, 256, 1, 256), (77, 256, 256, 8, 33), (130, 8, 256, 2, 100)]
+        for rows, cin, c, nh, cout in cases:
+            assert _C.lib().sihl_mlp_rows_supported(rows, cin, c, cout, nh, 2, 1) == 1
+    else:
+        ops_mod.MLP_KERNEL = "tile"
+        assert _C.lib().sihl_mlp_stages(stages) == 0
     try:
         for rows, cin, c, nh, cout in cases:
             m = mlp_mod.MLP(cin, [c] * nh + [cout], norm_layer=torch.nn.LayerNorm, activation_layer=torch.nn.SiLU)
@@ -284,6 +295,7 @@ def test_whole_mlp_one_launch(stages):
             _close(one, h, 3e-2, 3e-2, f"whole MLP vs torch {rows}x{cin}>{c}x{nh}>{cout}")
     finally:
         mlp_mod.FUSE_WHOLE_MLP = True
+        ops_mod.MLP_KERNEL = kernel_before
         _C.lib().sihl_mlp_stages(3)
 
 

@@ -47,7 +47,10 @@ for rows, cout in ((174592, 1), (3200, 80)):
         mlp_mod.FUSE_WHOLE_MLP = False
         t_lay = timed(lambda: m(x))
         mlp_mod.FUSE_WHOLE_MLP = True
-        line = f"rows {rows} -> {cout}: layered {t_lay:7.1f} us"
+        ops.MLP_KERNEL = "rows"
+        t_rows = timed(lambda: m(x))
+        ops.MLP_KERNEL = "tile"
+        line = f"rows {rows} -> {cout}: layered {t_lay:7.1f} us | registers (mlp_rows) {t_rows:7.1f} us"
         for st in (2, 3):
             lib.sihl_mlp_stages(st)
             line += f" | one launch, {st} stages {timed(lambda: m(x)):7.1f} us"
@@ -62,6 +65,27 @@ for rows, cout in ((174592, 1), (3200, 80)):
         def direct():
             lib.sihl_mlp_fwd(x.data_ptr(), 256, rows, 256, 256, 4, plan.w, plan.bias, plan.gamma, plan.beta, 1e-5, 2, cout,
                              out.data_ptr(), cp, 1, torch.cuda.current_stream().cuda_stream)
+        ops.MLP_KERNEL = "rows"
+        plan_r = ops._mlp_plan(lin, lns, torch.bfloat16)
+        ops.MLP_KERNEL = "tile"
+
+        def direct_rows():
+            lib.sihl_mlp_rows_fwd(x.data_ptr(), 256, rows, 256, 256, 4, plan_r.w_rows, plan_r.bias, plan_r.gamma, plan_r.beta,
+                                  1e-5, 2, cout, out.data_ptr(), cp, 1, torch.cuda.current_stream().cuda_stream)
+        line = "   direct launches, registers kernel, start delay x4096 cycles:"
+        for d in (0,):
+            lib.sihl_mlp_rows_delay(d)
+            line += f" {d}: {timed(direct_rows, 50):6.1f} |"
+        lib.sihl_mlp_rows_delay(0)
+        print(line, flush=True)
+        if os.environ.get("SIHL_HIP_LIB"):
+            line = "   registers kernel ablations:"
+            for name, mode in (("all", 0), ("no LN", 1), ("no DMA", 2), ("no MFMA", 4), ("no LN no DMA", 3), ("no LN no MFMA", 5),
+                               ("no DMA no MFMA", 6), ("skeleton", 7)):
+                lib.sihl_mlp_rows_debug(mode)
+                line += f" {name} {timed(direct_rows, 50):6.1f} |"
+            lib.sihl_mlp_rows_debug(0)
+            print(line, flush=True)
         m = None
         timed_ = lambda: timed(direct, 50)  # noqa: E731
         line = f"   direct launches:"
