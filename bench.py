@@ -259,8 +259,6 @@ def main():
                          "file right before the timed steps")
     ap.add_argument("--main-priority", type=int, default=0,
                     help="A/B: run the step on a user stream of this HIP priority (-1 = high) instead of the default stream")
-    ap.add_argument("--pointwise-persistent", action="store_true",
-                    help="A/B: HBM-bound 1x1 convs on the persistent weight-stationary kernel (csrc/conv_pw.hip, opt-in)")
     ap.add_argument("--no-fused-loss", action="store_true",
                     help="A/B: the detection loss as PyTorch device ops instead of the fused sihl_od_loss kernel")
     ap.add_argument("--lean", action="store_true",
@@ -320,8 +318,6 @@ def main():
 
     import types
 
-    if args.pointwise_persistent:
-        _C.lib().sihl_conv2d_pw_enable(1)
     if args.no_fused_loss:
         from sihl_amd.heads import object_detection as _od
         _od.FUSED_LOSS = False

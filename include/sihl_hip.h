@@ -53,8 +53,6 @@ int sihl_conv2d_stat_rows(long M);
 int sihl_conv2d_force_register_staging(int on);
 /* Tuning hook: pixel-tile size of the LDS-DMA kernel for Cout > 128 (0 = heuristic, 128 or 256). */
 int sihl_conv2d_tile_override(int bm);
-int sihl_conv2d_p8_enable(int on);   /* tuning / test hook: 0 = two-stage 256x256 tile instead of the persistent 8-phase kernel */
-int sihl_conv2d_pw_enable(int mode); /* tuning / test hook: 0 = HBM-bound pointwise layers take the one-tile-per-workgroup kernel, not csrc/conv_pw.hip; 1 = default rule; 2 = every shape the kernel can run */
 int sihl_conv2d_nbuf_override(int n); /* tuning hook: LDS stages of the narrow-tile kernels, 0 = default */
 /* Tuning ablation of the LDS-DMA kernel (results are INVALID when non-zero): 1 = no in-loop DMA, 2 = no ds_read/MFMA. */
 int sihl_conv2d_debug(int mode);
@@ -208,13 +206,6 @@ int sihl_maxpool3x3s2_bwd(const void* dy, const void* idx, void* dx, int N, int 
                           hipStream_t stream);
 
 /* ---- MLP hidden layers: y = act(LayerNorm(z)*gamma + beta) over [rows][C] (object_detection.py:51-61) ----- */
-/* Linear -> LayerNorm -> activation of one MLP layer in ONE launch (heads/object_detection.py:51-61):
- * y = act(LayerNorm(x W^T + b) * gamma + beta), x [rows][Cin], w [Cout][Cin], Cout <= 256.  z (nullable) = the Linear's
- * output, mean / rstd (nullable, together) = row statistics - what sihl_layernorm_act_bwd reads.  Same arithmetic as
- * sihl_conv2d_fwd followed by sihl_layernorm_act. */
-int sihl_linear_ln_act(const void* x, const void* w, const float* bias, const float* gamma, const float* beta, float eps,
-                       int act, void* z, void* y, float* mean, float* rstd, long rows, int Cin, int Cout, int dtype,
-                       hipStream_t stream);
 /* The WHOLE MLP in one launch, inference (heads/object_detection.py:51-61,108-121; SURVEY App. D counts an MLP as one op):
  * out[rows][out_stride] = Linear_n(act(LN(Linear_{n-1}(... act(LN(Linear_0(x)))...)))) with a 128-row activation tile
  * resident in LDS across the layers and the weight panels streamed through an LDS ring (csrc/mlp_fused.hip).  bf16 only;

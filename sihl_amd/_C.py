@@ -22,15 +22,12 @@ SIGNATURES = {
     "sihl_conv2d_stat_rows": (I, [L]),
     "sihl_conv2d_force_register_staging": (I, [I]),
     "sihl_conv2d_tile_override": (I, [I]),
-    "sihl_conv2d_p8_enable": (I, [I]),
-    "sihl_conv2d_pw_enable": (I, [I]),
     "sihl_conv2d_nbuf_override": (I, [I]),
     "sihl_conv2d_debug": (I, [I]),
     "sihl_conv2d_strided_classes_enable": (I, [I]),
     "sihl_conv2d_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, P, P, P, I, P, L, L, P]),
     "sihl_od_loss_ws_bytes": (L, [L, I]),
     "sihl_od_loss": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, P, P, P, P, P, I, P, L, P]),
-    "sihl_linear_ln_act": (I, [P, P, P, P, P, F, I, P, P, P, P, L, I, I, I, P]),
     "sihl_mlp_fwd_supported": (I, [L, I, I, I, I, I, I]),
     "sihl_mlp_fwd": (I, [P, L, L, I, I, I, P, P, P, P, F, I, I, P, I, I, P]),
     "sihl_mlp_rows_supported": (I, [L, I, I, I, I, I, I]),

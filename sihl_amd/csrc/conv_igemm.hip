@@ -28,13 +28,6 @@ int sihl_conv2d_force_register_staging(int on) { g_force_reg = on != 0; return 0
 // Tuning ablation (results invalid when non-zero): 1 = skip the in-loop DMA, 2 = skip ds_read/MFMA.
 int sihl_conv2d_debug(int mode) { g_dbg = mode; return 0; }
 
-// Tuning / test hook: 0 = the two-stage 256x256 tile instead of the persistent 8-phase kernel (conv_p8.h).
-int sihl_conv2d_p8_enable(int on) { sihl_p8_set_enabled(on != 0); return 0; }
-
-// Tuning / test hook: 0 = HBM-bound pointwise layers take the one-tile-per-workgroup kernel instead of conv_pw.hip;
-// 1 = default rule; 2 = conv_pw.hip for every shape it can run, however small (tests).
-int sihl_conv2d_pw_enable(int mode) { sihl_pw_set_enabled(mode); return 0; }
-
 // Tuning hook: LDS stages of the narrow-tile LDS-DMA kernels (0 = default, 2..4).
 int sihl_conv2d_nbuf_override(int n) { g_nbuf = n; return 0; }
 
@@ -107,40 +100,8 @@ int sihl_conv2d_fwd_ws(const void* in, const void* wt, const float* bias, void* 
   }
   p.splits = 1; p.partial = (float*)ws; p.partial_bytes = ws ? ws_bytes : 0;
   p.add = nullptr; p.add_stride = 1; p.add_H = p.add_W = 0;
-  p.ln_gamma = p.ln_beta = nullptr; p.ln_out = nullptr; p.ln_mean = p.ln_rstd = nullptr; p.ln_eps = 0.f; p.ln_act = 0;
   p.w_ntaps = KH * KW; p.w_kw = KW; p.w_ky0 = p.w_kx0 = 0; p.w_kys = p.w_kxs = 1;
   p.out_s = 1; p.out_py = p.out_px = 0; p.out_W = p.Wo;
-  if (dtype == SIHL_F32) return sihl_conv_dispatch_f32(p, stream);
-  if (dtype == SIHL_BF16) return sihl_conv_dispatch_bf16(p, stream);
-  return SIHL_EARG;
-}
-
-// y = act(LayerNorm(x W^T + b) * gamma + beta) over rows in ONE launch (the MLP layer of the dense heads:
-// torchvision.ops.MLP = Linear -> LayerNorm -> SiLU, heads/object_detection.py:51-61).  x [rows][Cin], w [Cout][Cin],
-// Cout <= 256 and a multiple of the 16-byte vector.  z (nullable) receives the Linear's output (what the backward's
-// LayerNorm gradient reads), mean / rstd (nullable) the row statistics.  act: SIHL_ACT_NONE / RELU / SILU.
-int sihl_linear_ln_act(const void* x, const void* w, const float* bias, const float* gamma, const float* beta, float eps,
-                       int act, void* z, void* y, float* mean, float* rstd, long rows, int Cin, int Cout, int dtype,
-                       hipStream_t stream) {
-  if (!x || !w || !gamma || !beta || !y || rows <= 0 || rows > (1L << 30) || Cin <= 0 || Cout <= 0 || Cout > 256)
-    return SIHL_EARG;
-  if (act != SIHL_ACT_NONE && act != SIHL_ACT_RELU && act != SIHL_ACT_SILU) return SIHL_EARG;
-  if (Cout % (dtype == SIHL_BF16 ? 8 : 4)) return SIHL_EARG;
-  if ((mean == nullptr) != (rstd == nullptr)) return SIHL_EARG;
-  ConvParams p;
-  p.in = x; p.wt = w; p.out = z; p.bias = bias;
-  p.pre_scale = p.pre_shift = p.post_scale = p.post_shift = nullptr;
-  p.stats = nullptr;
-  p.N = 1; p.H = 1; p.W = (int)rows; p.Cin = Cin; p.Cout = Cout; p.KH = p.KW = 1;
-  p.stride = 1; p.pad = 0; p.dil = 1; p.Ho = 1; p.Wo = (int)rows; p.M = (int)rows;
-  p.act = SIHL_ACT_NONE; p.stats_mode = 0;
-  p.gridM = p.gridN = 0; p.in_dilate = 1; p.dbg = 0;
-  p.out_image_stride = (long)rows * Cout;
-  p.splits = 1; p.partial = nullptr; p.partial_bytes = 0;
-  p.add = nullptr; p.add_stride = 1; p.add_H = p.add_W = 0;
-  p.w_ntaps = 1; p.w_kw = 1; p.w_ky0 = p.w_kx0 = 0; p.w_kys = p.w_kxs = 1;
-  p.out_s = 1; p.out_py = p.out_px = 0; p.out_W = (int)rows;
-  p.ln_gamma = gamma; p.ln_beta = beta; p.ln_out = y; p.ln_mean = mean; p.ln_rstd = rstd; p.ln_eps = eps; p.ln_act = act;
   if (dtype == SIHL_F32) return sihl_conv_dispatch_f32(p, stream);
   if (dtype == SIHL_BF16) return sihl_conv_dispatch_bf16(p, stream);
   return SIHL_EARG;
@@ -198,7 +159,6 @@ int sihl_conv2d_dgrad_add(const void* dout, const void* wt_t, void* din, const v
   p.add = add;
   p.add_stride = add ? add_stride : 1;
   p.add_H = (H + add_stride - 1) / add_stride; p.add_W = (W + add_stride - 1) / add_stride;
-  p.ln_gamma = p.ln_beta = nullptr; p.ln_out = nullptr; p.ln_mean = p.ln_rstd = nullptr; p.ln_eps = 0.f; p.ln_act = 0;
   p.w_ntaps = KH * KW; p.w_kw = KW; p.w_ky0 = p.w_kx0 = 0; p.w_kys = p.w_kxs = 1;
   p.out_s = 1; p.out_py = p.out_px = 0; p.out_W = W;
   // 3x3 / stride 2 / pad 1 (the strided convs of the ResNet stages): four parity classes of output pixels, each a small

@@ -253,58 +253,6 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t
     }
     return;
   }
-  if constexpr (BN == 256 && !ADD) if (p.ln_gamma) {
-    // Linear -> LayerNorm -> act: one tile row is one output row (n0 == 0, Cout <= 256).  A row's 16-byte chunks sit on
-    // consecutive lanes (32 lanes for bf16, the whole wave for fp32), so the two row reductions are lane shuffles; same
-    // arithmetic as layernorm_act_kernel (two-pass variance, 1 / sqrt, hardware exp2 / rcp sigmoid) on the same staged
-    // values, so fused and unfused agree bit for bit in what they normalise.
-    static_assert(BM * CHUNKS % NTHREADS == 0, "every lane takes part in every row reduction");
-    static_assert(NTHREADS % CHUNKS == 0, "a thread keeps its channel chunk: gamma / beta live in registers");
-    T* __restrict__ yo = (T*)p.ln_out;
-    const float inv_c = 1.f / (float)p.Cout;
-    const int ch = tid % CHUNKS, co = ch * VEC;
-    const bool cok = co < p.Cout;  // Cout % VEC == 0
-    float ga[VEC], be[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) { ga[e] = cok ? p.ln_gamma[co + e] : 0.f; be[e] = cok ? p.ln_beta[co + e] : 0.f; }
-    for (int idx = tid; idx < BM * CHUNKS; idx += NTHREADS) {
-      const int row = idx / CHUNKS;
-      const int m = m0 + row;
-      float v[VEC];
-      const uint4 raw = *(const uint4*)(epi + row * EPI_STRIDE + ch * 16);
-      unpack16(raw, v, T());
-      float sum = 0.f;
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) { v[e] = cok ? v[e] : 0.f; sum += v[e]; }
-#pragma unroll
-      for (int o = CHUNKS / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-      const float mu = sum * inv_c;
-      float q = 0.f;
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) { const float d = cok ? v[e] - mu : 0.f; q += d * d; }
-#pragma unroll
-      for (int o = CHUNKS / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
-      const float rs = 1.f / sqrtf(q * inv_c + p.ln_eps);
-      if (m < p.M && cok) {
-        float y[VEC];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          float t = (v[e] - mu) * rs * ga[e] + be[e];
-          if (p.ln_act == SIHL_ACT_SILU) {
-            const float ex = __builtin_amdgcn_exp2f(fminf(-t * 1.4426950408889634f, 126.f));  // = fast_sigmoid
-            t = t * __builtin_amdgcn_rcpf(1.f + ex);
-          } else if (p.ln_act == SIHL_ACT_RELU) {
-            t = fmaxf(t, 0.f);
-          }
-          y[e] = t;
-        }
-        *(uint4*)(yo + (long)m * p.Cout + co) = pack16(y, T());
-        if (out) *(uint4*)(out + (long)m * p.Cout + co) = raw;
-        if (ch == 0 && p.ln_mean) { p.ln_mean[m] = mu; p.ln_rstd[m] = rs; }
-      }
-    }
-    return;
-  }
   if (vec_ok && p.out_s == 1 && p.out_image_stride == (long)hw_o * p.Cout) {
     // dense output: row m starts at m * Cout (no per-chunk division by the image size)
     for (int idx = tid; idx < BM * CHUNKS; idx += NTHREADS) {
@@ -1081,19 +1029,6 @@ int dispatch(const ConvParams& p, hipStream_t stream) {
   const long in_bytes = (long)p.N * p.H * p.W * p.Cin * (long)sizeof(T);
   const long wt_bytes = (long)p.Cout * p.KH * p.KW * p.Cin * (long)sizeof(T);
   const bool dma = !g_force_reg && in_bytes < (1L << 31) && wt_bytes < (1L << 31) && p.KH * p.KW <= 32;
-  if (p.ln_gamma) {  // fused LayerNorm epilogue: the tile must hold whole rows
-    if (!dma || p.Cout > 256 || p.splits != 1) return SIHL_EARG;
-    const long wgs = (p.M + 127) / 128;
-    if (wgs <= 256) return launch_dma<T, 128, 256, 2, 2, 3>(p, stream);  // alone on its CU: three stages (144 KiB)
-    // big grids: ONE stage (66-132 KiB with the epilogue staging), so that two workgroups share a CU and one's row
-    // normalisation runs under the other's loads and multiplies (the thin-K pointwise rule of stages_for)
-    return launch_dma<T, 128, 256, 2, 2, 1>(p, stream);
-  }
-  if constexpr (sizeof(T) == 2) {
-    // HBM-bound pointwise layers (short contraction into >= 128 channels over many pixels): the persistent
-    // weight-stationary kernel of conv_pw.hip
-    if (dma && g_tile_override == 0 && !g_nbuf && sihl_pw_eligible(p)) return sihl_pw_launch(p, stream);
-  }
   if (!dma) {
     if (p.Cout > 128) return launch_reg<T, 256, 2, 2>(p, stream);
     if (p.Cout > 64) return launch_reg<T, 128, 2, 2>(p, stream);
@@ -1110,10 +1045,7 @@ int dispatch(const ConvParams& p, hipStream_t stream) {
       // window lose (r2 128>512: 63 -> 66, L3 3x3: 156 -> 182)
       if (g_tile_override == 0 && !(g_rules_off & 2) && p.M >= 256 * 256 && p.KH * p.KW == 1 && p.Cin <= 256 && p.Cout <= 256)
         return launch_n128<T>(p, stream);
-      if (g_tile_override == 256 || (g_tile_override == 0 && p.M >= 256 * 256)) {
-        if (sihl_p8_eligible(p)) return sihl_p8_launch(p, stream);
-        return launch_dma<T, 256, 256, 4, 2>(p, stream);
-      }
+      if (g_tile_override == 256 || (g_tile_override == 0 && p.M >= 256 * 256)) return launch_dma<T, 256, 256, 4, 2>(p, stream);
     }
     if constexpr (sizeof(T) == 2) {  // tuning: 128 pixels x 256 channels on 8 waves (2 x 4), 2 / 3 LDS stages
       if (g_tile_override == 2562) return launch_dma<T, 128, 256, 2, 4, 2>(p, stream);

@@ -1,4 +1,4 @@
-// Launch parameters shared by the implicit-GEMM conv kernels (conv_igemm_impl.h, conv_p8.h, conv_pw.hip).
+// Launch parameters shared by the implicit-GEMM conv kernels (conv_igemm_impl.h, conv_small.hip).
 #pragma once
 #include "common.h"
 
@@ -37,20 +37,7 @@ struct ConvParams {
   // kx*w_kxs) - and scatters output pixel (i, j) to (i*out_s + out_py, j*out_s + out_px) of an out_W-wide image.
   int w_ntaps, w_kw, w_ky0, w_kys, w_kx0, w_kxs;  // defaults: KH*KW, KW, 0, 1, 0, 1
   int out_s, out_py, out_px, out_W;                // defaults: 1, 0, 0, Wo
-  // Fused LayerNorm + activation over the output row (Linear -> LayerNorm -> SiLU of torchvision.ops.MLP,
-  // heads/object_detection.py:51-61): when ln_gamma is set the tile spans the whole row (Cout <= 256, one channel tile),
-  // `out` (may be null) receives the pre-norm row z, ln_out the normalised + activated row, ln_mean / ln_rstd
-  // (may be null) the row statistics the backward needs.
-  const float* ln_gamma; const float* ln_beta; void* ln_out; float* ln_mean; float* ln_rstd; float ln_eps; int ln_act;
   int add_stride;   // > 1: the addend is [N][add_H][add_W][Cout] and lands on output pixels (y, x) with y % add_stride
   int add_H, add_W; // == 0 and x % add_stride == 0 only (input gradient of a strided 1x1 projection: zero elsewhere)
 };
 
-// conv_p8.hip: persistent 256x256 bf16 kernel
-bool sihl_p8_eligible(const ConvParams& p);
-int sihl_p8_launch(const ConvParams& p, hipStream_t stream);
-void sihl_p8_set_enabled(bool on);
-// conv_pw.hip: persistent weight-stationary pointwise kernel (1x1, stride 1, Cin <= 256, bf16)
-bool sihl_pw_eligible(const ConvParams& p);
-int sihl_pw_launch(const ConvParams& p, hipStream_t stream);
-void sihl_pw_set_enabled(int mode);  // 0 off, 1 on, 2 on for every eligible shape (tests)

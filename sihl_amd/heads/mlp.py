@@ -9,11 +9,6 @@ from torch import Tensor, nn
 from sihl_amd import ops
 
 
-FUSE_LINEAR_LN = False  # opt-in: measured SLOWER than the kernel pair (eval head forward, bs 32: 1.35 vs 0.82 ms bf16, 2.88 vs
-# 2.08 ms fp32, profiles/r02_fused_mlp_layer.txt) - the row normalisation in the conv epilogue (two 32-lane shuffle
-# reductions per 16-byte chunk, one workgroup or two per CU) costs more than the LayerNorm kernel's extra pass over HBM
-
-
 FUSE_WHOLE_MLP = True  # test / A-B switch: False = layer by layer (Linear kernel + LayerNorm kernel) in inference too
 
 
@@ -57,11 +52,7 @@ class MLP(nn.Sequential):
                     act = mods[i + 2]
                     if not isinstance(act, nn.SiLU):
                         raise NotImplementedError("LayerNorm is fused with SiLU only")
-                    if FUSE_LINEAR_LN and ops.linear_ln_act_fusable(h, m.weight):
-                        # one launch per layer: the Linear's epilogue normalises and activates the row it produced
-                        h = ops.linear_ln_act(h, m.weight, m.bias, nxt.weight, nxt.bias, nxt.eps, "silu")
-                    else:
-                        h = ops.layernorm_act(ops.linear(h, m.weight, m.bias), nxt.weight, nxt.bias, nxt.eps, "silu")
+                    h = ops.layernorm_act(ops.linear(h, m.weight, m.bias), nxt.weight, nxt.bias, nxt.eps, "silu")
                     i += 3
                     continue
                 h = ops.linear(h, m.weight, m.bias)

@@ -1017,62 +1017,6 @@ class LayerNormActFn(torch.autograd.Function):
         return dz, dgamma, dbeta, None, None
 
 
-class LinearLNActFn(torch.autograd.Function):
-    """y = act(LayerNorm(x @ W^T + b) * gamma + beta) in ONE launch (sihl_linear_ln_act: the conv kernel's epilogue
-    normalises the row it has just produced); backward = the LayerNorm+act backward kernel on the saved pre-norm rows,
-    then the Linear's three gradients, exactly as the unfused pair."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, eps, act):
-        xd = x.detach().contiguous()
-        rows, Cin = xd.shape
-        Cout = weight.shape[0]
-        prep = prepared(weight, xd.dtype)
-        if prep is not None:
-            w, ctx.wt = prep.w.view(prep.w.shape[0], -1), prep.wt
-        else:
-            w, ctx.wt = weight.detach().to(xd.dtype).contiguous(), None
-        b = bias.detach().float().contiguous() if bias is not None else None
-        g, be = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-        need = any(ctx.needs_input_grad)
-        y = torch.empty((rows, Cout), dtype=xd.dtype, device=xd.device)
-        z = torch.empty_like(y) if need else None
-        mean = torch.empty(rows, dtype=torch.float32, device=xd.device) if need else None
-        rstd = torch.empty_like(mean) if need else None
-        rc = _C.lib().sihl_linear_ln_act(_p(xd), _p(w), _p(b), _p(g), _p(be), eps, ACT[act], _p(z), _p(y), _p(mean),
-                                         _p(rstd), rows, Cin, Cout, _dt(xd), _stream())
-        check(rc, "sihl_linear_ln_act")
-        if need:
-            ctx.save_for_backward(xd, w, z, g, be, mean, rstd)
-        ctx.act, ctx.has_bias = act, bias is not None
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, w, z, g, be, mean, rstd = ctx.saved_tensors
-        dy = dy.contiguous()
-        rows, Cin = x.shape
-        Cout = w.shape[0]
-        lib = _C.lib()
-        ws = workspace(lib.sihl_layernorm_act_bwd_ws_bytes(rows, Cout), z.device)
-        dz = torch.empty_like(z)
-        dgamma = torch.empty(Cout, dtype=torch.float32, device=z.device)
-        dbeta = torch.empty_like(dgamma)
-        rc = lib.sihl_layernorm_act_bwd(_p(z), _p(dy), _p(dz), rows, Cout, _p(g), _p(be), _p(mean), _p(rstd),
-                                        ACT[ctx.act], _p(dgamma), _p(dbeta), _dt(z), _p(ws), ws.numel(), _stream())
-        check(rc, "sihl_layernorm_act_bwd")
-        dx = dw = db = None
-        if ctx.needs_input_grad[1]:  # first: on the side stream it then runs beside the input gradient below
-            dw = conv2d_wgrad_raw(x.view(1, 1, rows, Cin), dz.view(1, 1, rows, Cout), 1, 1, 1, 0, 1).view(Cout, Cin)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dz, off_chain=True)
-        if ctx.needs_input_grad[0]:
-            wt = ctx.wt if ctx.wt is not None else weight_for_dgrad(w.view(Cout, 1, 1, Cin), flip=False)
-            dx, _ = conv2d_raw(dz.view(1, 1, rows, Cout), wt)
-            dx = dx.view(rows, Cin)
-        return dx, dw, db, dgamma, dbeta, None, None
-
-
 MLP_KERNEL = os.environ.get("SIHL_MLP_KERNEL", "rows")  # A/B switch: "rows" = activations in registers (mlp_rows.hip),
 # "tile" = the 128-row LDS tile of mlp_fused.hip
 
@@ -1159,17 +1103,6 @@ def mlp_fused(x: Tensor, linears, norms, act: Optional[str]) -> Tensor:
                                norms[0].eps if norms else 0.0, ACT[act], Cout, _p(out), Cp, BF16, _stream())
     check(rc, "sihl_mlp_fwd")
     return out if Cp == Cout else out[:, :Cout]
-
-
-def linear_ln_act_fusable(x: Tensor, weight: Tensor) -> bool:
-    """The fused layer needs the whole output row in one 256-channel tile and 16-byte channel vectors."""
-    vec = 8 if x.dtype == torch.bfloat16 else 4
-    Cout, Cin = weight.shape
-    return Cout <= 256 and Cout % vec == 0 and Cin % vec == 0 and x.numel() * x.element_size() < (1 << 31)
-
-
-def linear_ln_act(x, weight, bias, gamma, beta, eps, act):
-    return LinearLNActFn.apply(x, weight, bias, gamma, beta, eps, act)
 
 
 def linear(x, weight, bias):

@@ -185,52 +185,6 @@ def test_fusion_nodes_borders_and_odd_sizes(dtype, rtol, atol):
         _close(plain.permute(0, 3, 1, 2), blur, rtol, atol, f"plain blur {N}x{H}x{W}x{C}")
 
 
-@pytest.mark.parametrize("dtype,rtol,atol", DTYPES)
-def test_linear_ln_act_fused_layer(dtype, rtol, atol):
-    """One MLP layer (Linear -> LayerNorm -> SiLU, heads/object_detection.py:51-61) as ONE launch against (a) the
-    unfused kernel pair - the same arithmetic on the same stored values: equal to summation-order rounding - and (b) a
-    plain fp32 PyTorch computation, forward and all five gradients; rows cover partial last tiles, a grid above and
-    below one workgroup per CU, and a narrow head (32 channels: the golden cases' width)."""
-    ops = _ops()
-    g = torch.Generator().manual_seed(4)
-    for rows, cin, cout in [(300, 256, 256), (5456 * 8, 256, 256), (1000, 64, 32), (129, 32, 32)]:
-        x = torch.randn(rows, cin, generator=g).to(dtype).float().requires_grad_(True)
-        w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).requires_grad_(True)
-        b = torch.randn(cout, generator=g).requires_grad_(True)
-        ga = (1 + 0.3 * torch.randn(cout, generator=g)).requires_grad_(True)
-        be = (0.3 * torch.randn(cout, generator=g)).requires_grad_(True)
-        z = F.linear(x, w.to(dtype).float(), b)
-        if dtype == torch.bfloat16:
-            z = z.bfloat16().float()  # the pre-norm row is stored in the compute dtype in both GPU variants
-        ref = F.silu(F.layer_norm(z, (cout,), ga, be))
-        cot = torch.randn(ref.shape, generator=g).to(dtype).float()
-        ref.backward(cot)
-        outs = []
-        for fused in (True, False):
-            xd = x.detach().to(DEV, dtype).requires_grad_(True)
-            ps = [t.detach().to(DEV).requires_grad_(True) for t in (w, b, ga, be)]
-            assert ops.linear_ln_act_fusable(xd, ps[0])
-            if fused:
-                y = ops.linear_ln_act(xd, ps[0], ps[1], ps[2], ps[3], 1e-5, "silu")
-            else:
-                y = ops.layernorm_act(ops.linear(xd, ps[0], ps[1]), ps[2], ps[3], 1e-5, "silu")
-            y.backward(cot.to(DEV, dtype))
-            outs.append([y] + [xd.grad] + [p_.grad for p_ in ps])
-        names = ["y", "dx", "dw", "db", "dgamma", "dbeta"]
-        refs = [ref, x.grad, w.grad, b.grad, ga.grad, be.grad]
-        for n, a, c, r in zip(names, outs[0], outs[1], refs):
-            _close(a, c, 1e-5 if dtype == torch.float32 else 1e-2, 1e-5 if dtype == torch.float32 else 1e-2, f"fused vs unfused {n} {rows}x{cin}>{cout}")
-            _close(a, r, rtol * 2, atol * 2, f"fused vs torch {n} {rows}x{cin}>{cout}")
-    # inference: no pre-norm rows, no statistics written
-    with torch.no_grad():
-        xd = torch.randn(777, 256, generator=g).to(DEV, dtype)
-        wd, bd = (torch.randn(256, 256, generator=g) / 16).to(DEV), torch.randn(256, generator=g).to(DEV)
-        gd, bed = torch.ones(256, device=DEV), torch.zeros(256, device=DEV)
-        a = ops.linear_ln_act(xd, wd, bd, gd, bed, 1e-5, "silu")
-        c = ops.layernorm_act(ops.linear(xd, wd, bd), gd, bed, 1e-5, "silu")
-        _close(a, c, 1e-5 if dtype == torch.float32 else 1e-2, 1e-5 if dtype == torch.float32 else 1e-2, "eval fused vs unfused")
-
-
 @pytest.mark.parametrize("stages", [2, 3, "rows"])
 def test_whole_mlp_one_launch(stages):
     """torchvision.ops.MLP as the dense heads use it ([Linear -> LayerNorm -> SiLU] x n -> Linear,
@@ -618,80 +572,6 @@ def test_od_loss_fused_matches_autograd(dtype, rtol, atol):
         _close(got, ref, 2e-5, 2e-5, f"losses (none_matched={none_matched})")
         for n, x, y in zip(("d_loc", "d_iou", "d_box", "d_cls"), b, a):
             _close(x.grad, y.grad, max(rtol, 1e-4), max(atol, 1e-5), f"{n} (none_matched={none_matched})")
-
-
-# ------------------------------------------------------------------ persistent pointwise kernel (csrc/conv_pw.hip)
-PW_SHAPES = [
-    # N, H, W, Cin, Cout          (M = N*H*W pixel rows; gridN = Cout / 128 channel tiles)
-    (4, 64, 64, 64, 256),         # r1 expansion shape, one K chunk, ring of 6
-    (2, 97, 53, 64, 128),         # ragged M (10282 = 80 tiles + 42 rows): zero-filled rows, masked statistics
-    (8, 32, 32, 128, 512),        # two K chunks, four channel tiles
-    (1, 1, 21824, 256, 256),      # the MLP linear: four K chunks, ring of 3
-    (4, 32, 32, 192, 1024),       # three K chunks, eight channel tiles
-    (16, 64, 64, 256, 128),       # one channel tile
-]
-
-
-@pytest.mark.parametrize("shape", PW_SHAPES)
-@pytest.mark.parametrize("act,stats", [(None, 0), ("relu", 0), (None, 1), ("relu", 2), ("silu", 0)])
-def test_pointwise_persistent_kernel_matches_tile_kernel(shape, act, stats):
-    """conv_pw_kernel (one resident workgroup per CU, weights in LDS, A streamed through a DMA ring) against the
-    one-tile-per-workgroup kernel on the same inputs: bit-identical outputs, BatchNorm partial rows equal to fp32 rounding
-    (another summation order), and both within
-    bf16 rounding of an fp32 matmul."""
-    from sihl_amd import _C, ops
-
-    N, H, W, Cin, Cout = shape
-    g = torch.Generator(device="cuda").manual_seed(Cin * 7 + Cout)
-    x = torch.randn(N, H, W, Cin, device="cuda", dtype=torch.bfloat16, generator=g)
-    w = (torch.randn(Cout, 1, 1, Cin, device="cuda", generator=g) * Cin ** -0.5).bfloat16()
-    b = torch.randn(Cout, device="cuda", generator=g) if stats == 0 else None
-    lib = _C.lib()
-    try:
-        lib.sihl_conv2d_pw_enable(0)
-        y0, s0 = ops.conv2d_raw(x, w, b, 1, 0, 1, act=act, stats_mode=stats)
-        lib.sihl_conv2d_pw_enable(2)  # the persistent kernel whatever the size (the default rule wants >= 1024 tiles)
-        y1, s1 = ops.conv2d_raw(x, w, b, 1, 0, 1, act=act, stats_mode=stats)
-    finally:
-        lib.sihl_conv2d_pw_enable(1)
-    torch.cuda.synchronize()
-    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
-    if stats:  # full tiles sum (even rows, odd rows) pairs: the same fp32 partial sums in another order
-        torch.testing.assert_close(s0, s1, rtol=2e-6, atol=1e-4)
-    ref = x.float().reshape(-1, Cin) @ w.float().reshape(Cout, Cin).T
-    if b is not None:
-        ref = ref + b
-    ref = {"relu": torch.relu, "silu": torch.nn.functional.silu}.get(act, lambda t: t)(ref)
-    torch.testing.assert_close(y1.float().reshape(-1, Cout), ref, rtol=2e-2, atol=2e-2)
-    if stats:
-        rows = s1.shape[0]
-        pad = rows * 128 - ref.shape[0]
-        r = torch.nn.functional.pad(ref, (0, 0, 0, pad)).reshape(rows, 128, Cout)
-        torch.testing.assert_close(s1[:, 0], r.sum(1), rtol=1e-2, atol=5e-2)
-        torch.testing.assert_close(s1[:, 1], (r * r).sum(1), rtol=1e-2, atol=5e-2)
-
-
-def test_pointwise_persistent_kernel_default_rule_full_size():
-    """BASELINE size: ResNet50 layer1's 64 -> 256 expansion at batch 32, 128x128 (4096 pixel tiles x 2 channel tiles, 32
-    tiles per resident workgroup) under the DEFAULT dispatch rule against the tile kernel, plus the launch profiler's
-    record that the two runs were different kernels (the persistent one must not be slower than 0.9x the tile kernel)."""
-    from sihl_amd import _C, ops
-
-    lib = _C.lib()
-    x = torch.randn(32, 128, 128, 64, device="cuda", dtype=torch.bfloat16)
-    w = (torch.randn(256, 1, 1, 64, device="cuda") * 0.125).bfloat16()
-    try:
-        lib.sihl_conv2d_pw_enable(0)
-        y0, s0 = ops.conv2d_raw(x, w, None, 1, 0, 1, stats_mode=1)
-        lib.sihl_conv2d_pw_enable(1)
-        y1, s1 = ops.conv2d_raw(x, w, None, 1, 0, 1, stats_mode=1)
-    finally:
-        lib.sihl_conv2d_pw_enable(1)
-    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
-    torch.testing.assert_close(s0, s1, rtol=2e-6, atol=1e-4)
-    # checksum of checksums against fp32 on a slice (the whole product is 34 GFLOP in fp32: a slice keeps the test fast)
-    ref = x[5].float().reshape(-1, 64) @ w.float().reshape(256, 64).T
-    torch.testing.assert_close(y1[5].float().reshape(-1, 256), ref, rtol=2e-2, atol=2e-2)
 
 
 # ------------------------------------------------------------------ BatchNorm + ReLU behind a foreign conv (the stem)

@@ -61,25 +61,6 @@ def test_conv_kernel_occupancy():
         assert found[key] >= want, f"conv_igemm_dma_kernel{key}: {found[key]} waves/SIMD, expected >= {want}"
 
 
-@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-def test_pointwise_kernel_inline_asm_hazards():
-    """conv_pw.hip issues loads AND stores through inline asm; both hazards were found in it."""
-    src = os.path.join(ROOT, "sihl_amd", "csrc", "conv_pw.hip")
-    asm = os.path.join(tempfile.mkdtemp(), "conv_pw.s")
-    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", src, "-o", asm],
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    from scan_sgpr_hazard import scan
-    text = open(asm).read()
-    os.remove(asm)
-    total, hits = scan(text)
-    assert total >= 100 and not hits, hits[:5]
-    # the scanner has teeth: strip the padding and the store-data hazard must show
-    stripped = text.replace("\ts_nop 1\n", "\n")
-    assert scan(stripped)[1], "scanner did not flag 16-byte stores whose data register is recycled at once"
-
-
 def test_hazard_scanner_on_synthetic_isa():
     """The scanner itself, on hand-written assembly: it must flag a descriptor reloaded by v_readlane right before an
     inline buffer instruction and a 16-byte store whose data register is overwritten next, and accept the padded forms."""

@@ -34,19 +34,6 @@ for dt in (torch.bfloat16, torch.float32):
         e[2].record()
         torch.cuda.synchronize()
     tn, th = e[0].elapsed_time(e[1]) / n, e[1].elapsed_time(e[2]) / n
-    from sihl_amd.heads import mlp as _mlp
-    _mlp.FUSE_LINEAR_LN = False  # A/B: Linear kernel + LayerNorm kernel per MLP layer
-    with torch.no_grad():
-        for _ in range(3):
-            out = head(feats)
-        torch.cuda.synchronize()
-        e[1].record()
-        for _ in range(n):
-            out = head(feats)
-        e[2].record()
-        torch.cuda.synchronize()
-    _mlp.FUSE_LINEAR_LN = True
-    print(f"{str(dt)[6:]:9s} head.forward with unfused MLP layers: {e[1].elapsed_time(e[2]) / n:.3f} ms (fused: {th:.3f})", flush=True)
     gflop = 32 * (45.64 + 3.69)
     print(f"{str(dt)[6:]:9s} neck {tn:.3f} ms  head.forward {th:.3f} ms  total {tn + th:.3f} ms  -> "
           f"{32 / (tn + th) * 1e3:.0f} img/s, {gflop / (tn + th):.0f} TFLOP/s algorithmic "

@@ -58,7 +58,7 @@ def scan(asm_text):
 
 def main():
     files = sys.argv[1:] or [os.path.join(CSRC, f) for f in ("conv_igemm_bf16.hip", "conv_igemm_f32.hip", "conv_wgrad.hip",
-                                                             "conv_p8.hip", "conv_pw.hip")]  # every user of dma.h / inline asm
+                                                             "mlp_fused.hip", "mlp_rows.hip")]  # every user of dma.h / inline asm
     bad = 0
     for f in files:
         with tempfile.TemporaryDirectory() as d:
