@@ -89,6 +89,7 @@ int sihl_conv2d_dgrad_add(const void* dout, const void* wt_t, void* din, const v
                           int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, int dtype, void* ws,
                           long ws_bytes, hipStream_t stream);
 int sihl_conv2d_splitk_enable(int on); /* tuning / test hook */
+int sihl_conv2d_small_enable(int on);  /* tuning / test hook: 0 = 3x3 convs of the small pyramid levels on the general kernel, not csrc/conv_small.hip */
 int sihl_conv2d_rules_off(int mask);   /* tuning hook: disable individual dispatch rules */
 
 /* Weight gradient (autograd of Conv2d.weight / Linear.weight): dw fp32 [Cout][KH][KW][Cin];

@@ -44,6 +44,7 @@ SIGNATURES = {
     "sihl_conv2d_dgrad_ws": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, L, P]),
     "sihl_conv2d_dgrad_add": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, L, P]),
     "sihl_conv2d_splitk_enable": (I, [I]),
+    "sihl_conv2d_small_enable": (I, [I]),
     "sihl_conv2d_rules_off": (I, [I]),
     "sihl_conv2d_wgrad_force_register_staging": (I, [I]),
     "sihl_conv2d_wgrad_ws_bytes": (L, [I, I, I, I, I, I, I, I, I, I, I, I]),

@@ -42,12 +42,17 @@ long sihl_conv2d_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW
   const int Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   if (Ho <= 0 || Wo <= 0) return 0;
   const long M = (long)N * Ho * Wo;
-  if (((M + 127) / 128) * ((Cout + 63) / 64) > 64) return 0;
-  return 9L * M * Cout * (long)sizeof(float);
+  const long small = M < (1L << 30) ? sihl_small_ws_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad, dil) : 0;
+  if (((M + 127) / 128) * ((Cout + 63) / 64) > 64) return small;
+  const long general = 9L * M * Cout * (long)sizeof(float);
+  return general > small ? general : small;
 }
 
 // Tuning hook: switch individual dispatch rules off (bit 0: single-stage narrow tiles, bit 1: thin pointwise -> 128x128).
 int sihl_conv2d_rules_off(int mask) { g_rules_off = mask; return 0; }
+
+// Tuning / test hook: 0 = the small pyramid levels' 3x3 convs take the general kernel instead of conv_small.hip.
+int sihl_conv2d_small_enable(int on) { sihl_small_set_enabled(on != 0); return 0; }
 
 // Tuning / test hook: 0 disables split-K.
 int sihl_conv2d_splitk_enable(int on) { g_splitk = on != 0; return 0; }

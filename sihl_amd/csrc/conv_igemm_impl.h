@@ -1029,6 +1029,10 @@ int dispatch(const ConvParams& p, hipStream_t stream) {
   const long in_bytes = (long)p.N * p.H * p.W * p.Cin * (long)sizeof(T);
   const long wt_bytes = (long)p.Cout * p.KH * p.KW * p.Cin * (long)sizeof(T);
   const bool dma = !g_force_reg && in_bytes < (1L << 31) && wt_bytes < (1L << 31) && p.KH * p.KW <= 32;
+  if constexpr (sizeof(T) == 2) {
+    // 3x3 convs of the small pyramid levels: halo-resident input patch, split-K finished inside the launch (conv_small.hip)
+    if (dma && g_tile_override == 0 && !g_nbuf && sihl_small_eligible(p)) return sihl_small_launch(p, stream);
+  }
   if (!dma) {
     if (p.Cout > 128) return launch_reg<T, 256, 2, 2>(p, stream);
     if (p.Cout > 64) return launch_reg<T, 128, 2, 2>(p, stream);

@@ -37,7 +37,15 @@ struct ConvParams {
   // kx*w_kxs) - and scatters output pixel (i, j) to (i*out_s + out_py, j*out_s + out_px) of an out_W-wide image.
   int w_ntaps, w_kw, w_ky0, w_kys, w_kx0, w_kxs;  // defaults: KH*KW, KW, 0, 1, 0, 1
   int out_s, out_py, out_px, out_W;                // defaults: 1, 0, 0, Wo
+  int small_nch;    // conv_small.hip (3x3 on the small pyramid levels): channel chunks one workgroup walks
   int add_stride;   // > 1: the addend is [N][add_H][add_W][Cout] and lands on output pixels (y, x) with y % add_stride
   int add_H, add_W; // == 0 and x % add_stride == 0 only (input gradient of a strided 1x1 projection: zero elsewhere)
 };
 
+// conv_small.hip: halo-resident 3x3 kernel of the small pyramid levels (bf16)
+bool sihl_small_eligible(const ConvParams& p);
+int sihl_small_launch(const ConvParams& p, hipStream_t stream);
+void sihl_small_set_enabled(bool on);
+long sihl_small_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil);
+// conv_igemm_bf16.hip: the finishing launch of a split-K conv (sums the fp32 slices, runs the epilogue), for conv_small.hip
+int sihl_conv_splitk_finish_bf16(const ConvParams& p, hipStream_t stream);

@@ -80,7 +80,7 @@ class deferred_bn_counters:
 
 
 def workspace(nbytes: int, device) -> Tensor:
-    """Grow-only scratch buffer per device (kernels are stream-ordered, so one buffer is shared)."""
+    """Grow-only scratch buffer per device and stream (kernels are stream-ordered, so one buffer is shared)."""
     key = (device.index, _stream())
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:

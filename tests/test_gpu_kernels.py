@@ -447,12 +447,14 @@ def test_conv_splitk_matches_single_pass(shape, dtype, tol):
     bias = torch.randn(Cout, device="cuda")
     lib = _C.lib()
     outs = {}
+    lib.sihl_conv2d_small_enable(0)  # (the square small levels would otherwise take conv_small.hip either way)
     for on in (0, 1):
         lib.sihl_conv2d_splitk_enable(on)
         try:
             outs[on] = ops.conv2d_raw(x, w, bias, 1, K // 2, 1, act="relu", stats_mode=2)
         finally:
             lib.sihl_conv2d_splitk_enable(1)
+    lib.sihl_conv2d_small_enable(1)
     ref = torch.relu(torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias,
                                                 padding=K // 2)).permute(0, 2, 3, 1)
     rtol = 1e-4 if dtype == torch.float32 else 2e-2
@@ -461,6 +463,63 @@ def test_conv_splitk_matches_single_pass(shape, dtype, tol):
         torch.testing.assert_close(y.float(), ref, rtol=rtol, atol=rtol * float(ref.abs().max()))
         torch.testing.assert_close(stats[:, 0].sum(0), ref.reshape(-1, Cout).sum(0), rtol=rtol, atol=rtol * float(ref.abs().sum(0).max()))
     torch.testing.assert_close(outs[1][1].sum(0), outs[0][1].sum(0), rtol=1e-3, atol=1e-3 * float(outs[0][1].abs().max()))
+
+
+@pytest.mark.parametrize("mode", ["eval", "train_act_norm", "train_norm_act", "bias_silu", "plain"])
+@pytest.mark.parametrize("shape", [(32, 16, 256, 256), (32, 8, 256, 256), (32, 4, 256, 256), (3, 4, 256, 256), (5, 8, 64, 128),
+                                   (2, 16, 128, 64), (1, 16, 192, 64), (9, 4, 512, 64)])
+def test_conv_small_levels(shape, mode):
+    """conv_small.hip - the 3x3 convs of the small pyramid levels (16x16 / 8x8 / 4x4 maps; halo-resident input patch, weight
+    ring per kernel row, split-K over the channel chunks with the general kernel's finishing launch) -
+    against the general kernel on the same operands (same bf16 operands, fp32 sums in another order) and an fp32 PyTorch
+    conv, for every epilogue the conv blocks use; ragged last tiles (3 maps of 4x4 = 48 of 128 pixels), one to eight
+    channel chunks with and without the split; and run-to-run bit-identity over 30 launches (the slices are added in slice
+    order)."""
+    from sihl_amd import _C, ops
+    N, W, Cin, Cout = shape
+    g = torch.Generator(device="cuda").manual_seed(N * 1000 + W * 10 + Cin)
+    x = torch.randn(N, W, W, Cin, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) * (9 * Cin) ** -0.5).bfloat16()
+    bias = torch.randn(Cout, device="cuda", generator=g)
+    sc, sh = torch.rand(Cout, device="cuda", generator=g) + 0.5, torch.randn(Cout, device="cuda", generator=g)
+    kw = {"eval": dict(act="relu", post=(sc, sh)), "train_act_norm": dict(act="relu", stats_mode=2),
+          "train_norm_act": dict(stats_mode=1), "bias_silu": dict(bias=bias, act="silu", pre=(sc, sh)), "plain": {}}[mode]
+    bias_arg = kw.pop("bias", None)
+    lib = _C.lib()
+    run = lambda: ops.conv2d_raw(x, w, bias_arg, 1, 1, 1, **kw)  # noqa: E731
+    try:
+        lib.sihl_conv2d_small_enable(0)
+        y0, s0 = run()
+    finally:
+        lib.sihl_conv2d_small_enable(1)
+    lib.sihl_profile_enable(1)
+    y1, s1 = run()
+    torch.cuda.synchronize()
+    lib.sihl_profile_enable(0)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias_arg, padding=1).permute(0, 2, 3, 1)
+    pre = ref
+    if "pre" in kw:
+        ref = ref * sc + sh
+    ref = {"relu": torch.relu, "silu": F.silu}.get(kw.get("act"), lambda t: t)(ref)
+    stat_src = pre if kw.get("stats_mode") == 1 else ref
+    if "post" in kw:
+        ref = ref * sc + sh
+    scale = float(ref.abs().max())
+    torch.testing.assert_close(y1.float(), ref, rtol=2e-2, atol=2e-2 * scale)
+    torch.testing.assert_close(y1.float(), y0.float(), rtol=1e-2, atol=1e-2 * scale)  # one bf16 ulp where the fp32 sums differ
+    assert float((y1.float() - y0.float()).abs().mean()) < 1e-3 * scale
+    if kw.get("stats_mode"):
+        rows = (N * W * W + 127) // 128
+        assert s1.shape == (rows, 2, Cout)
+        src = F.pad(stat_src.reshape(-1, Cout), (0, 0, 0, rows * 128 - N * W * W)).reshape(rows, 128, Cout)
+        torch.testing.assert_close(s1[:, 0], src.sum(1), rtol=1e-3, atol=1e-3 * float(src.abs().sum(1).max()))
+        torch.testing.assert_close(s1[:, 1], (src * src).sum(1), rtol=1e-3, atol=1e-3 * float((src * src).sum(1).max()))
+        torch.testing.assert_close(s1, s0, rtol=1e-4, atol=1e-4 * float(s0.abs().max()))
+    for _ in range(30):
+        y2, s2 = run()
+        assert torch.equal(y2.view(torch.int16), y1.view(torch.int16))
+        if s1 is not None:
+            assert torch.equal(s2, s1)
 
 
 @pytest.mark.parametrize("dtype,rtol,atol", DTYPES)

@@ -1,14 +1,39 @@
-import os, sys, types, torch
+"""Developer probe (GPU box): same-box A/B of the north-star forward (bench.north_star_forward: BiFPN + ObjectDetection.forward,
+eval, bs 32, 512^2, bf16) under the library's switches - boxes of the pool differ by several per cent, so only alternating
+runs in one process compare.  Usage: python tools/ns_ab.py [rounds]"""
+import sys
+import types
+
+import torch
+
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-import bench, sihl_amd
+import bench  # noqa: E402
+import sihl_amd  # noqa: E402
+from sihl_amd import _C, ops  # noqa: E402
+
 dev = torch.device("cuda", 0)
 ns = types.SimpleNamespace(ResNetBackbone=sihl_amd.ResNetBackbone, BiFPN=sihl_amd.layers.BiFPN,
                            ObjectDetection=sihl_amd.heads.ObjectDetection, SihlModel=sihl_amd.SihlModel)
 model = bench.build_model(ns, dev)
-from sihl_amd import ops
 prep = ops.PreparedWeights(model, torch.bfloat16)
-for rnd in range(3):
-    for cat in ("", "1"):
-        sihl_amd.heads.object_detection.CAT_LATERALS = bool(cat)
+lib = _C.lib()
+
+
+def variant(small, mlp):
+    lib.sihl_conv2d_small_enable(small)
+    ops.MLP_KERNEL = mlp
+
+
+VARIANTS = [("default (small-level conv, register MLP)", 1, "rows"), ("general conv on P5-P7", 0, "rows"),
+            ("LDS-tile MLP", 1, "tile"), ("round-2 kernels (general conv, LDS-tile MLP)", 0, "tile")]
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+res = {name: [] for name, _, _ in VARIANTS}
+for rnd in range(rounds):
+    for name, small, mlp in VARIANTS:
+        variant(small, mlp)
         r = bench.north_star_forward(model, dev, torch.bfloat16, 32, 512, iters=40)
-        print("cat" if cat else "into-flat", round(r["ms"], 3), flush=True)
+        res[name].append(r["ms"])
+variant(1, "rows")
+for name, _, _ in VARIANTS:
+    v = res[name]
+    print(f"{name:48s} " + " ".join(f"{x:.3f}" for x in v) + f"   median {sorted(v)[len(v) // 2]:.3f} ms", flush=True)
