@@ -46,6 +46,7 @@ SIGNATURES = {
     "sihl_conv2d_splitk_enable": (I, [I]),
     "sihl_conv2d_small_enable": (I, [I]),
     "sihl_conv2d_rules_off": (I, [I]),
+    "sihl_conv2d_krot": (I, [I]),
     "sihl_conv2d_wgrad_force_register_staging": (I, [I]),
     "sihl_conv2d_wgrad_ws_bytes": (L, [I, I, I, I, I, I, I, I, I, I, I, I]),
     "sihl_conv2d_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P, L, P]),

@@ -477,8 +477,12 @@ __global__ __launch_bounds__(WM * WN * 64, (conv_min_waves<BM, BN>())) void conv
   // split-K (tiny pyramid levels): this workgroup multiplies the stages [s_first, s_first + nstages)
   const int total_stages = nchunks * ntaps;
   const int per_split = (total_stages + p.splits - 1) / p.splits;
-  const int s_first = (int)blockIdx.y * per_split;
-  const int nstages = min(total_stages, s_first + per_split) - s_first;
+  // k_rotate (unsplit launches): workgroup L starts its K loop at stage k_rotate * L mod total and wraps around.  Every workgroup
+  // reads the SAME weight panel, and workgroups started together walk it in lockstep: each 32 KiB weight stage is then
+  // requested by all of an XCD's workgroups at once.  Rotated starts spread the panel's lines over the L2 channels at any
+  // moment (the fp32 sum of a tile is taken in another stage order: deterministic, tile by tile).
+  const int s_first = p.k_rotate ? (int)(((unsigned)L * (unsigned)p.k_rotate) % (unsigned)total_stages) : (int)blockIdx.y * per_split;
+  const int nstages = p.k_rotate ? total_stages : min(total_stages, s_first + per_split) - s_first;
 
   const v4i_t in_rsrc = make_rsrc(p.in, (unsigned)((long)p.N * p.H * p.W * p.Cin * (long)sizeof(T)));
   const v4i_t wt_rsrc = make_rsrc(p.wt, (unsigned)((long)p.Cout * p.w_ntaps * p.Cin * (long)sizeof(T)));
@@ -547,7 +551,7 @@ __global__ __launch_bounds__(WM * WN * 64, (conv_min_waves<BM, BN>())) void conv
   int c_kc = s_first / ntaps, c_tap = s_first % ntaps - 1, c_ky = 0, c_kx = -1;  // state "one before s_first"
   if (c_tap >= 0) { c_ky = c_tap / p.KW; c_kx = c_tap - c_ky * p.KW; }
   auto stage_setup = [&](int /*s*/, int buf) {
-    if (++c_tap == ntaps) { c_tap = 0; c_ky = 0; c_kx = 0; ++c_kc; }
+    if (++c_tap == ntaps) { c_tap = 0; c_ky = 0; c_kx = 0; if (++c_kc == nchunks) c_kc = 0; }
     else if (++c_kx == p.KW) { c_kx = 0; ++c_ky; }
     n_kc = c_kc; n_tap = c_tap; n_ky = c_ky; n_kx = c_kx;
     n_tapbit = 1u << n_tap;
@@ -909,6 +913,8 @@ int launch_dma(const ConvParams& p0, hipStream_t stream) {
                          p.stats_mode == 0 && !p.bias && !p.pre_scale && !p.post_scale;
   const void* late_add = (p.add && !fused_add && p.splits == 1) ? p.add : nullptr;  // split-K adds in its finisher
   if (late_add) p.add = nullptr;
+  p.k_rotate = (!(g_rules_off & 4) && p.splits == 1 && p.gridM * p.gridN >= 64 &&
+                ((p.Cin + KCB / (int)sizeof(T) - 1) / (KCB / (int)sizeof(T))) * p.KH * p.KW >= 8) ? g_krot : 0;
   auto kern = p.in_dilate > 1 ? conv_igemm_dma_kernel<T, BM, BN, WM, WN, true, NBUF>
                               : conv_igemm_dma_kernel<T, BM, BN, WM, WN, false, NBUF>;
   if constexpr (CAN_ADD) {

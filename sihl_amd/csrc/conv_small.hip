@@ -95,16 +95,25 @@ __global__ __launch_bounds__(STHREADS, 1) void conv_small_kernel(const ConvParam
     const int kx = row >> 6, col = row & 63;
     b_off[j] = (unsigned)((((long)(n0 + col) * 9 + kx) * p.Cin) * 2 + ((pos ^ ((col >> 1) & 7)) << 4));
   }
-  auto issue_a = [&](int c, int buf) {  // channel chunk kc0 + c of the patch
+  // Every workgroup of a launch reads the same weights; started together they would request the same 24 KiB stage at the
+  // same moment.  Workgroup (tile_m, tile_n) therefore walks its chunks from chunk rc on and its kernel rows from row rk on
+  // (wrapping around): the fp32 sum of a tile is taken in another order, tile by tile (deterministic).
+  const int rot = p.k_rotate ? tile_m * p.gridN + tile_n : 0;
+  const int rc = rot % nch, rk = (rot / nch) % 3;
+  auto issue_a = [&](int c, int buf) {  // channel chunk kc0 + (c + rc) % nch of the patch
     const unsigned dst = lds_base + buf * Geo::A_BYTES + wave * Geo::APW * 1024;
-    const unsigned delta = (unsigned)((kc0 + c) * SKCB);
+    const int cc = c + rc >= nch ? c + rc - nch : c + rc;
+    const unsigned delta = (unsigned)((kc0 + cc) * SKCB);
 #pragma unroll
     for (int j = 0; j < Geo::APW; ++j) dma16(((a_ok >> j) & 1) ? a_off[j] + delta : OOB, dst + j * 1024, in_rsrc);
   };
   auto issue_b = [&](int s) {  // stage s = (chunk s / 3, kernel row s % 3) into ring slot s % 3
-    const int c = s / 3, ky = s - 3 * c;
+    const int c = s / 3;
+    int ky = s - 3 * c + rk, cc = c + rc;
+    if (ky >= 3) ky -= 3;
+    if (cc >= nch) cc -= nch;
     const unsigned dst = ring_base + (s % 3) * SB_STAGE + wave * SB_PIECES * 1024;
-    const unsigned delta = (unsigned)((ky * 3 * p.Cin) * 2 + (kc0 + c) * SKCB);
+    const unsigned delta = (unsigned)((ky * 3 * p.Cin) * 2 + (kc0 + cc) * SKCB);
 #pragma unroll
     for (int j = 0; j < SB_PIECES; ++j) dma16(b_off[j] + delta, dst + j * 1024, wt_rsrc);
   };
@@ -143,11 +152,12 @@ __global__ __launch_bounds__(STHREADS, 1) void conv_small_kernel(const ConvParam
     if (ky == 0 && c + 1 < nch && !(SIHL_DBG(p) & 1)) issue_a(c + 1, (c + 1) & 1);
     const char* As = smem + (c & 1) * Geo::A_BYTES;
     const char* Bs = smem + 2 * Geo::A_BYTES + (s % 3) * SB_STAGE + fr * SKCB;
+    const int kyr = ky + rk >= 3 ? ky + rk - 3 : ky + rk;  // the kernel row this stage's weights belong to
     if (!(SIHL_DBG(p) & 2))
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-      const char* ap = As + (pbase + ky * Geo::PW + kx) * SKCB;
-      const int f = Geo::swz(pr0 + ky, pc0 + kx);
+      const char* ap = As + (pbase + kyr * Geo::PW + kx) * SKCB;
+      const int f = Geo::swz(pr0 + kyr, pc0 + kx);
       const char* bp = Bs + kx * SBN * SKCB;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -309,6 +319,7 @@ int sihl_small_launch(const ConvParams& p0, hipStream_t stream) {
   p.splits = small_splits(p);
   p.small_nch = p.Cin / 64 / p.splits;
   p.dbg = g_dbg;  // read by the kernel in SIHL_TUNING builds only
+  p.k_rotate = g_krot != 0;
   const double flops = 2.0 * p.M * (double)p.Cout * 9 * p.Cin;
   const double bytes = ((double)p.N * p.H * p.W * p.Cin + (double)p.M * p.Cout + (double)p.Cout * 9 * p.Cin) * 2.0;
   sihl_prof_begin(SIHL_PROF_CONV, SIHL_BF16, flops, bytes, stream);

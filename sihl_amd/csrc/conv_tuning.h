@@ -10,7 +10,8 @@ struct ConvTuning {
   int nbuf;              // tuning hook: LDS stages of the narrow LDS-DMA tiles (0 = default)
   bool splitk;           // tuning / test hook: split-K for tiny pyramid levels
   bool strided_classes;  // tuning / test hook: parity-class dgrad of 3x3 stride-2 convs (else zero-dilated read)
-  int rules_off;         // tuning hook: bit 0 = no single-stage narrow tiles, bit 1 = no 128x128 routing of thin pointwise layers
+  int rules_off;         // tuning hook: bit 0 = no single-stage narrow tiles, bit 1 = no 128x128 routing of thin pointwise layers, bit 2 = K loops in lockstep
+  int krot;              // tuning hook: stage stride between neighbouring workgroups' K-loop starts (default 13)
 };
 extern ConvTuning sihl_conv_tuning;
 #define g_force_reg (sihl_conv_tuning.force_reg)
@@ -20,6 +21,7 @@ extern ConvTuning sihl_conv_tuning;
 #define g_splitk (sihl_conv_tuning.splitk)
 #define g_strided_classes (sihl_conv_tuning.strided_classes)
 #define g_rules_off (sihl_conv_tuning.rules_off)
+#define g_krot (sihl_conv_tuning.krot)
 
 constexpr int BM128 = 128;  // pixels per BatchNorm partial row
 

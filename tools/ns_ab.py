@@ -19,21 +19,24 @@ prep = ops.PreparedWeights(model, torch.bfloat16)
 lib = _C.lib()
 
 
-def variant(small, mlp):
+def variant(small, mlp, krot=13, mlp_rot=1):
     lib.sihl_conv2d_small_enable(small)
+    lib.sihl_conv2d_krot(krot)
     ops.MLP_KERNEL = mlp
 
 
-VARIANTS = [("default (small-level conv, register MLP)", 1, "rows"), ("general conv on P5-P7", 0, "rows"),
-            ("LDS-tile MLP", 1, "tile"), ("round-2 kernels (general conv, LDS-tile MLP)", 0, "tile")]
+VARIANTS = [("default (small-level conv, register MLP, rotated K loops)", 1, "rows", 13, 1),
+            ("conv K loops in lockstep", 1, "rows", 0, 1),
+            ("general conv on P5-P7", 0, "rows", 13, 1), ("LDS-tile MLP", 1, "tile", 13, 1),
+            ("round-2 kernels (general conv, LDS-tile MLP, lockstep)", 0, "tile", 0, 0)]
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-res = {name: [] for name, _, _ in VARIANTS}
+res = {v[0]: [] for v in VARIANTS}
 for rnd in range(rounds):
-    for name, small, mlp in VARIANTS:
-        variant(small, mlp)
+    for name, small, mlp, krot, mrot in VARIANTS:
+        variant(small, mlp, krot, mrot)
         r = bench.north_star_forward(model, dev, torch.bfloat16, 32, 512, iters=40)
         res[name].append(r["ms"])
-variant(1, "rows")
-for name, _, _ in VARIANTS:
+variant(1, "rows", 13, 1)
+for name in res:
     v = res[name]
-    print(f"{name:48s} " + " ".join(f"{x:.3f}" for x in v) + f"   median {sorted(v)[len(v) // 2]:.3f} ms", flush=True)
+    print(f"{name:64s} " + " ".join(f"{x:.3f}" for x in v) + f"   median {sorted(v)[len(v) // 2]:.3f} ms", flush=True)
