@@ -227,6 +227,14 @@ int sihl_mlp_fwd(const void* x, long x_stride, long rows, int Cin, int C, int nh
  * [0-3, 8-11, 4-7, 12-15] - the order in which a lane's accumulators hold a row's channels); w[0] is plain. */
 int sihl_mlp_rows_supported(long rows, int Cin, int C, int Cout, int nhidden, int act, int dtype);
 int sihl_mlp_rows_delay(int n); /* tuning hook: start delay of alternate workgroups, x 4096 cycles */
+/* Up to 4 such MLPs in ONE launch (the class / box heads of a detection head: the same few thousand rows, each MLP alone
+ * fills a tenth of the chip for the same 35 us); same activation for all, they may share x. */
+typedef struct sihl_mlp_call {
+  const void* x; long x_stride; long rows; int Cin, C, nhidden, Cout, out_stride; float eps;
+  const void* const* w; const float* const* bias; const float* const* gamma; const float* const* beta;
+  void* out;
+} sihl_mlp_call;
+int sihl_mlp_rows_fwd_multi(const sihl_mlp_call* calls, int n, int act, int dtype, hipStream_t stream);
 int sihl_mlp_rows_debug(int mode); /* timing ablations, `make TUNING=1` builds only (results invalid when non-zero) */
 int sihl_mlp_permute_k(const void* w_in, void* w_out, long Cout, int K, hipStream_t stream);
 int sihl_mlp_rows_fwd(const void* x, long x_stride, long rows, int Cin, int C, int nhidden, const void* const* w,

@@ -47,6 +47,12 @@ struct MlpRowsParams {
 #define MLPR_DBG(p) 0
 #endif
 
+constexpr int MLPR_MAXN = 4;  // MLPs per launch
+struct MlpRowsBatch {
+  MlpRowsParams p[MLPR_MAXN];
+  int first_block[MLPR_MAXN + 1];  // workgroups first_block[k] .. first_block[k + 1] - 1 run MLP k
+};
+
 constexpr int RBM = 128, RTHREADS = 256, RKCB = 128, RKCE = 64;
 constexpr int RSTAGE = 256 * RKCB;  // one weight stage: 256 out-channels x 64 k (32 KiB)
 constexpr int RRING = 2 * RSTAGE;
@@ -91,13 +97,19 @@ __device__ __forceinline__ void mlp_rows_stage(f32x16_t (&acc)[8], const uint4 (
 // Hidden layers are full width (C == 256: 8 blocks, compile-time - a run-time block count puts the accumulators behind
 // branches and hipcc then spills them).
 template <int SILU, int LASTB>
-__global__ __launch_bounds__(RTHREADS, 2) void mlp_rows_kernel(const MlpRowsParams p, const float floor_, const int delay) {
+__global__ __launch_bounds__(RTHREADS, 2) void mlp_rows_kernel(const MlpRowsBatch pb, const float floor_, const int delay) {
+  // several MLPs in one launch (the class and box heads of a detection head run over the same few thousand rows: each
+  // alone fills a tenth of the chip for the same 35 us)
+  int which = 0;
+#pragma unroll
+  for (int k = 1; k < MLPR_MAXN; ++k) which += (int)blockIdx.x >= pb.first_block[k] ? 1 : 0;
+  const MlpRowsParams& p = pb.p[which];
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
-  const int m0 = blockIdx.x * RBM;
+  const int m0 = ((int)blockIdx.x - pb.first_block[which]) * RBM;
   const unsigned lds_base = (unsigned)(unsigned long)(lds_ptr_t)smem;
   // fp32 vectors behind the ring: bias[nhidden + 1][256], gamma[nhidden][256], beta[nhidden][256] (zeros beyond the widths)
   float* pbias = (float*)(smem + RRING);
@@ -295,8 +307,10 @@ __global__ void mlp_permute_k_kernel(const uint2* __restrict__ in, uint2* __rest
 int g_mlp_rows_delay = 0;
 int g_mlp_rows_dbg = 0;
 template <int SILU, int LASTB>
-int launch_mlp_rows(const MlpRowsParams& p, float floor_, hipStream_t stream) {
-  const int lds = RRING + (3 * p.nhidden + 1) * 256 * (int)sizeof(float);
+int launch_mlp_rows(const MlpRowsBatch& pb, int n, float floor_, hipStream_t stream) {
+  int nh = 0;
+  for (int k = 0; k < n; ++k) nh = pb.p[k].nhidden > nh ? pb.p[k].nhidden : nh;
+  const int lds = RRING + (3 * nh + 1) * 256 * (int)sizeof(float);
   if (lds > 160 * 1024) return SIHL_EARG;
   static int attr_lds = 0;
   if (lds > attr_lds) {
@@ -304,7 +318,7 @@ int launch_mlp_rows(const MlpRowsParams& p, float floor_, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_lds = lds;
   }
-  hipLaunchKernelGGL((mlp_rows_kernel<SILU, LASTB>), dim3((p.rows + RBM - 1) / RBM), dim3(RTHREADS), lds, stream, p, floor_, g_mlp_rows_delay);
+  hipLaunchKernelGGL((mlp_rows_kernel<SILU, LASTB>), dim3(pb.first_block[n]), dim3(RTHREADS), lds, stream, pb, floor_, g_mlp_rows_delay);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
 }
@@ -339,41 +353,69 @@ int sihl_mlp_permute_k(const void* w_in, void* w_out, long Cout, int K, hipStrea
   return SIHL_OK;
 }
 
+// One MLP of a sihl_mlp_rows_fwd_multi launch (include/sihl_hip.h: sihl_mlp_call)
+struct sihl_mlp_call {
+  const void* x; long x_stride; long rows; int Cin, C, nhidden, Cout, out_stride; float eps;
+  const void* const* w; const float* const* bias; const float* const* gamma; const float* const* beta;
+  void* out;
+};
+
+// n <= 4 MLPs in ONE launch, each as sihl_mlp_rows_fwd (same activation for all; they may share x).
+int sihl_mlp_rows_fwd_multi(const sihl_mlp_call* calls, int n, int act, int dtype, hipStream_t stream) {
+  if (!calls || n < 1 || n > MLPR_MAXN) return SIHL_EARG;
+  MlpRowsBatch pb;
+  int maxco = 0, blocks = 0;
+  for (int k = 0; k < MLPR_MAXN; ++k) pb.first_block[k] = 0x7fffffff;
+  for (int k = 0; k < n; ++k) {
+    const sihl_mlp_call& c = calls[k];
+    if (!c.x || !c.out || !c.w || !c.bias || !c.gamma || !c.beta) return SIHL_EARG;
+    if (!sihl_mlp_rows_supported(c.rows, c.Cin, c.C, c.Cout, c.nhidden, act, dtype)) return SIHL_EARG;
+    if (c.out_stride < c.Cout || c.out_stride % 8 || c.out_stride > 256 || c.x_stride < c.Cin || c.x_stride % 8) return SIHL_EARG;
+    MlpRowsParams& p = pb.p[k];
+    p.x = c.x; p.out = c.out; p.x_stride = c.x_stride; p.out_stride = c.out_stride;
+    p.rows = (int)c.rows; p.Cin = c.Cin; p.C = c.C; p.Cout = c.Cout; p.nhidden = c.nhidden; p.eps = c.eps;
+    p.dbg = g_mlp_rows_dbg;
+    for (int l = 0; l <= MLPR_MAXL; ++l) { p.w[l] = nullptr; p.bias[l] = nullptr; }
+    for (int l = 0; l < MLPR_MAXL; ++l) { p.gamma[l] = nullptr; p.beta[l] = nullptr; }
+    for (int l = 0; l <= c.nhidden; ++l) {
+      if (!c.w[l]) return SIHL_EARG;
+      p.w[l] = c.w[l];
+      p.bias[l] = c.bias[l];
+    }
+    for (int l = 0; l < c.nhidden; ++l) {
+      if (!c.gamma[l] || !c.beta[l]) return SIHL_EARG;
+      p.gamma[l] = c.gamma[l];
+      p.beta[l] = c.beta[l];
+    }
+    pb.first_block[k] = blocks;
+    blocks += (p.rows + RBM - 1) / RBM;
+    maxco = c.Cout > maxco ? c.Cout : maxco;
+  }
+  for (int k = n; k <= MLPR_MAXN; ++k) pb.first_block[k] = k == n ? blocks : 0x7fffffff;
+  pb.first_block[n] = blocks;
+  for (int k = n; k < MLPR_MAXN; ++k) pb.p[k] = pb.p[0];
+  const float floor_ = act == SIHL_ACT_RELU ? 0.f : -__builtin_inff();
+#define SIHL_MLPR(S)                                                          \
+  do {                                                                        \
+    if (maxco <= 32) return launch_mlp_rows<S, 1>(pb, n, floor_, stream);     \
+    if (maxco <= 96) return launch_mlp_rows<S, 3>(pb, n, floor_, stream);     \
+    return launch_mlp_rows<S, 8>(pb, n, floor_, stream);                      \
+  } while (0)
+  if (act == SIHL_ACT_SILU) SIHL_MLPR(1);
+  SIHL_MLPR(0);
+#undef SIHL_MLPR
+}
+
 // out[rows][out_stride] = Linear_n( act(LN(Linear_{n-1}( ... act(LN(Linear_0(x))) ... ))) ), one launch, activations in
 // registers.  Arguments as sihl_mlp_fwd, except: nhidden >= 1, C == 256, and w[l] for l >= 1 in the K order of
 // sihl_mlp_permute_k (w[0] plain).
 int sihl_mlp_rows_fwd(const void* x, long x_stride, long rows, int Cin, int C, int nhidden, const void* const* w,
                       const float* const* bias, const float* const* gamma, const float* const* beta, float eps, int act,
                       int Cout, void* out, int out_stride, int dtype, hipStream_t stream) {
-  if (!x || !out || !w || !bias || !gamma || !beta) return SIHL_EARG;
-  if (!sihl_mlp_rows_supported(rows, Cin, C, Cout, nhidden, act, dtype)) return SIHL_EARG;
-  if (out_stride < Cout || out_stride % 8 || out_stride > 256 || x_stride < Cin || x_stride % 8) return SIHL_EARG;
-  MlpRowsParams p;
-  p.x = x; p.out = out; p.x_stride = x_stride; p.out_stride = out_stride;
-  p.rows = (int)rows; p.Cin = Cin; p.C = C; p.Cout = Cout; p.nhidden = nhidden; p.eps = eps;
-  p.dbg = g_mlp_rows_dbg;
-  for (int l = 0; l <= MLPR_MAXL; ++l) { p.w[l] = nullptr; p.bias[l] = nullptr; }
-  for (int l = 0; l < MLPR_MAXL; ++l) { p.gamma[l] = nullptr; p.beta[l] = nullptr; }
-  for (int l = 0; l <= nhidden; ++l) {
-    if (!w[l]) return SIHL_EARG;
-    p.w[l] = w[l];
-    p.bias[l] = bias[l];
-  }
-  for (int l = 0; l < nhidden; ++l) {
-    if (!gamma[l] || !beta[l]) return SIHL_EARG;
-    p.gamma[l] = gamma[l];
-    p.beta[l] = beta[l];
-  }
-  const float floor_ = act == SIHL_ACT_RELU ? 0.f : -__builtin_inff();
-#define SIHL_MLPR(S)                                                        \
-  do {                                                                      \
-    if (Cout <= 32) return launch_mlp_rows<S, 1>(p, floor_, stream);        \
-    if (Cout <= 96) return launch_mlp_rows<S, 3>(p, floor_, stream);        \
-    return launch_mlp_rows<S, 8>(p, floor_, stream);                        \
-  } while (0)
-  if (act == SIHL_ACT_SILU) SIHL_MLPR(1);
-  SIHL_MLPR(0);
-#undef SIHL_MLPR
+  sihl_mlp_call c;
+  c.x = x; c.x_stride = x_stride; c.rows = rows; c.Cin = Cin; c.C = C; c.nhidden = nhidden; c.Cout = Cout;
+  c.out_stride = out_stride; c.eps = eps; c.w = w; c.bias = bias; c.gamma = gamma; c.beta = beta; c.out = out;
+  return sihl_mlp_rows_fwd_multi(&c, 1, act, dtype, stream);
 }
 
 }  // extern "C"

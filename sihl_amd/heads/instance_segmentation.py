@@ -20,7 +20,7 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from sihl_amd import ops
-from sihl_amd.heads.mlp import MLP
+from sihl_amd.heads.mlp import MLP, forward_many
 from sihl_amd.heads.object_detection import ObjectDetection
 from sihl_amd.layers.convblocks import Conv2dNormActivation
 
@@ -111,8 +111,9 @@ class InstanceSegmentation(nn.Module):
         sel = ops.gather_rows(flat, top_idx).view(B * K, -1)
         scores = top_vals.sigmoid()
         num_instances = (scores > 0.5).sum(dim=1)
-        classes = self.cls_head(sel).reshape(B, K, -1).float().argmax(dim=2)
-        masks = ops.iseg_mask_decode(self._mask_feats_nhwc(inputs), self.kernel_head(sel), top_idx,
+        cls_logits, kernels = forward_many([self.cls_head, self.kernel_head], sel)  # one launch in inference
+        classes = cls_logits.reshape(B, K, -1).float().argmax(dim=2)
+        masks = ops.iseg_mask_decode(self._mask_feats_nhwc(inputs), kernels, top_idx,
                                      self._level_hw(inputs), (H, W))
         return num_instances, scores, classes, masks
 

@@ -15,7 +15,7 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from sihl_amd import ops
-from sihl_amd.heads.mlp import MLP
+from sihl_amd.heads.mlp import MLP, forward_many
 from sihl_amd.heads.object_detection import ObjectDetection
 from sihl_amd.layers.convblocks import Conv2dNormActivation
 
@@ -120,8 +120,9 @@ class KeypointDetection(nn.Module):
         centres = offsets[top_idx.long().reshape(-1), :2]  # (B*K, 2)
         rel = self._grid(h, w, device)[None] - centres[:, :, None, None]
         feats = torch.cat([mask_feats[:, None].expand(B, K, c, h, w).reshape(B * K, c, h, w), rel], dim=1)
-        heat = dynamic_keypoint_net(feats, self.kernel_head(sel).float(), c, nk).reshape(B, K, nk, h, w)
-        presence = self.presence_head(sel).reshape(B, K, nk).float().sigmoid()
+        kernels, presence = forward_many([self.kernel_head, self.presence_head], sel)  # one launch in inference
+        heat = dynamic_keypoint_net(feats, kernels.float(), c, nk).reshape(B, K, nk, h, w)
+        presence = presence.reshape(B, K, nk).float().sigmoid()
         if output_heatmaps:
             return heat.flatten(3, 4).softmax(3).reshape(heat.shape)
         flat_idx = heat.flatten(3, 4).max(3).indices

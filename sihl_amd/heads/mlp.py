@@ -12,6 +12,30 @@ from sihl_amd import ops
 FUSE_WHOLE_MLP = True  # test / A-B switch: False = layer by layer (Linear kernel + LayerNorm kernel) in inference too
 
 
+def _parts(mlp):
+    mods = list(mlp)
+    linears = [m for m in mods if isinstance(m, nn.Linear)]
+    norms = [m for m in mods if isinstance(m, nn.LayerNorm)]
+    rest = [m for m in mods if not isinstance(m, (nn.Linear, nn.LayerNorm, nn.Dropout))]
+    act = "silu" if rest and all(isinstance(m, nn.SiLU) for m in rest) else (None if not rest else "?")
+    return linears, norms, rest, act
+
+
+def forward_many(mlps, x: Tensor):
+    """[m(x) for m in mlps] for MLPs that read the same rows - in inference as ONE launch when the register kernel covers
+    them all (ops.mlp_fused_multi), else one by one."""
+    if FUSE_WHOLE_MLP and not torch.is_grad_enabled() and len(mlps) > 1:
+        lead = x.shape[:-1]
+        h = x.reshape(-1, x.shape[-1])
+        parts = [_parts(m) for m in mlps]
+        acts = {p[3] for p in parts}
+        if len(acts) == 1 and "?" not in acts and all(len(p[2]) == len(p[1]) for p in parts):
+            outs = ops.mlp_fused_multi(h, [(p[0], p[1]) for p in parts], parts[0][3])
+            if outs is not None:
+                return [o.reshape(*lead, o.shape[-1]) for o in outs]
+    return [m(x) for m in mlps]
+
+
 class MLP(nn.Sequential):
     def __init__(self, in_channels: int, hidden_channels: List[int], norm_layer=None, activation_layer=nn.ReLU,
                  inplace=None, bias=True, dropout=0.0):

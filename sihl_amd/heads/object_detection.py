@@ -17,7 +17,7 @@ from torch.nn import functional as F
 
 from sihl_amd import ops
 from sihl_amd.heads.box_ops import complete_box_iou, complete_box_iou_loss
-from sihl_amd.heads.mlp import MLP
+from sihl_amd.heads.mlp import MLP, forward_many
 from sihl_amd.layers.convblocks import Conv2dNormActivation
 
 
@@ -93,8 +93,8 @@ class ObjectDetection(nn.Module):
         loc_logits = self.loc_head(flat.view(B * P, -1))  # (B*P, 1) view of a vector-padded buffer
         top_vals, top_idx = ops.topk_rows(loc_logits, B, P, K, estride=loc_logits.stride(0))
         sel = ops.gather_rows(flat, top_idx)
-        cls_logits = self.cls_head(sel.view(B * K, -1)).reshape(B, K, -1)
-        box_raw = self.box_head(sel.view(B * K, -1)).reshape(B, K, 4)
+        cls_logits, box_raw = forward_many([self.cls_head, self.box_head], sel.view(B * K, -1))  # one launch in inference
+        cls_logits, box_raw = cls_logits.reshape(B, K, -1), box_raw.reshape(B, K, 4)
         return ops.od_decode(top_vals, top_idx, cls_logits, box_raw, level_hw, (W, H))
 
     def get_saliency(self, inputs: List[Tensor]) -> Tensor:

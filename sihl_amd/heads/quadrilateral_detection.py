@@ -16,7 +16,7 @@ from torch.nn import functional as F
 
 from sihl_amd import ops
 from sihl_amd.heads.box_ops import complete_box_iou
-from sihl_amd.heads.mlp import MLP
+from sihl_amd.heads.mlp import MLP, forward_many
 from sihl_amd.layers.convblocks import Conv2dNormActivation
 
 
@@ -106,9 +106,10 @@ class QuadrilateralDetection(nn.Module):
         scores = top_vals.float().sigmoid()
         num_instances = (scores > 0.5).sum(dim=1)
         offsets, _ = self.get_offsets_and_levels(inputs)
-        quads = offsets[top_idx.long().reshape(-1)] + self.quad_head(sel).float().tanh()
+        quad_raw, cls_logits = forward_many([self.quad_head, self.class_head], sel)  # one launch in inference
+        quads = offsets[top_idx.long().reshape(-1)] + quad_raw.float().tanh()
         quads = quads * torch.tensor([[W, H] * 4], device=device, dtype=torch.float32)
-        classes = self.class_head(sel).float().reshape(B, K, -1).max(dim=2).indices
+        classes = cls_logits.float().reshape(B, K, -1).max(dim=2).indices
         return num_instances, scores, classes, quads.reshape(B, K, 4, 2)
 
     # ------------------------------------------------------------------ training

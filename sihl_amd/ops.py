@@ -1105,6 +1105,46 @@ def mlp_fused(x: Tensor, linears, norms, act: Optional[str]) -> Tensor:
     return out if Cp == Cout else out[:, :Cout]
 
 
+class _MlpCall(ctypes.Structure):  # sihl_mlp_call of include/sihl_hip.h
+    _fields_ = [("x", ctypes.c_void_p), ("x_stride", ctypes.c_long), ("rows", ctypes.c_long), ("Cin", ctypes.c_int),
+                ("C", ctypes.c_int), ("nhidden", ctypes.c_int), ("Cout", ctypes.c_int), ("out_stride", ctypes.c_int),
+                ("eps", ctypes.c_float), ("w", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("gamma", ctypes.c_void_p),
+                ("beta", ctypes.c_void_p), ("out", ctypes.c_void_p)]
+
+
+def mlp_fused_multi(x: Tensor, mlps, act: Optional[str]):
+    """Several MLPs over the SAME rows x in ONE launch (sihl_mlp_rows_fwd_multi: a detection head's class and box MLPs run
+    over the same few thousand selected rows; each alone fills a tenth of the chip for the same time).  mlps: list of
+    (linears, norms).  Returns the list of outputs, or None when a member is outside the register kernel's shapes (the
+    caller then runs them one by one)."""
+    if len(mlps) < 2 or len(mlps) > 4 or MLP_KERNEL != "rows":
+        return None
+    lib = _C.lib()
+    rows, Cin = x.shape
+    calls = (_MlpCall * len(mlps))()
+    outs, keep = [], []
+    for k, (linears, norms) in enumerate(mlps):
+        if not norms or not mlp_fused_supported(x, linears, norms, act):
+            return None
+        Cout, C = linears[-1].weight.shape[0], linears[0].weight.shape[0]
+        plan = _mlp_plan(linears, norms, x.dtype)
+        if plan.w_rows is None or not lib.sihl_mlp_rows_supported(rows, Cin, C, Cout, len(norms), ACT[act], BF16):
+            return None
+        Cp = (Cout + 7) // 8 * 8
+        out = torch.empty((rows, Cp), dtype=x.dtype, device=x.device)
+        c = calls[k]
+        c.x, c.x_stride, c.rows, c.Cin, c.C, c.nhidden, c.Cout, c.out_stride = _p(x), x.stride(0), rows, Cin, C, len(norms), Cout, Cp
+        c.eps = norms[0].eps
+        c.w, c.bias = ctypes.cast(plan.w_rows, ctypes.c_void_p), ctypes.cast(plan.bias, ctypes.c_void_p)
+        c.gamma, c.beta = ctypes.cast(plan.gamma, ctypes.c_void_p), ctypes.cast(plan.beta, ctypes.c_void_p)
+        c.out = _p(out)
+        keep.append(plan)
+        outs.append(out if Cp == Cout else out[:, :Cout])
+    check(lib.sihl_mlp_rows_fwd_multi(ctypes.cast(calls, ctypes.c_void_p), len(mlps), ACT[act], BF16, _stream()),
+          "sihl_mlp_rows_fwd_multi")
+    return outs
+
+
 def linear(x, weight, bias):
     return LinearFn.apply(x, weight, bias)
 

@@ -253,6 +253,28 @@ def test_whole_mlp_one_launch(stages):
         _C.lib().sihl_mlp_stages(3)
 
 
+def test_mlps_sharing_rows_in_one_launch():
+    """sihl_mlp_rows_fwd_multi: the class / box / a third MLP over the same selected rows in ONE launch must give exactly
+    what each gives in a launch of its own (same kernel, same arithmetic), also when their widths and depths differ."""
+    from sihl_amd.heads import mlp as mlp_mod
+    torch.manual_seed(3)
+    x = torch.randn(3200, 256, device=DEV).bfloat16()
+    mk = lambda nh, cout: mlp_mod.MLP(256, [256] * nh + [cout], norm_layer=torch.nn.LayerNorm,  # noqa: E731
+                                      activation_layer=torch.nn.SiLU).to(DEV).eval()
+    mlps = [mk(4, 80), mk(4, 4), mk(2, 169), mk(1, 1)]
+    with torch.no_grad():
+        alone = [m(x) for m in mlps]
+        for n in (2, 3, 4):
+            together = mlp_mod.forward_many(mlps[:n], x)
+            assert _ops().mlp_fused_multi(x.reshape(-1, 256), [mlp_mod._parts(m)[:2] for m in mlps[:n]], "silu") is not None
+            for a, b in zip(alone, together):
+                assert a.shape == b.shape and torch.equal(a, b)
+        # rows that are not a multiple of the 128-row tile, through the leading-dimension reshape
+        xs = x[:1000].reshape(10, 100, 256)
+        for a, b in zip([m(xs) for m in mlps[:2]], mlp_mod.forward_many(mlps[:2], xs)):
+            assert a.shape == b.shape == (10, 100, a.shape[-1]) and torch.equal(a, b)
+
+
 @pytest.mark.parametrize("dtype,rtol,atol", DTYPES)
 def test_linear_layernorm(dtype, rtol, atol):
     ops = _ops()
