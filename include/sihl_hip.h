@@ -280,9 +280,10 @@ int sihl_topk_rows(const void* x, int B, int P, int K, int estride, float* vals,
                    hipStream_t stream);
 int sihl_gather_rows(const void* src, const int* idx, void* out, int B, int P, int K, int C, int dtype,
                      hipStream_t stream);
-int sihl_od_decode(const float* top_vals, const int* top_idx, const void* cls_logits, const void* box_raw,
-                   const int* level_hw, int n_levels, int B, int K, int ncls, int full_w, int full_h, float* scores,
-                   long* classes, float* boxes, long* num_instances, int dtype, hipStream_t stream);
+int sihl_od_decode(const float* top_vals, const int* top_idx, const void* cls_logits, long cls_stride, const void* box_raw,
+                   long box_stride, const int* level_hw, int n_levels, int B, int K, int ncls, int full_w, int full_h,
+                   float* scores, long* classes, float* boxes, long* num_instances, int dtype, hipStream_t stream);
+/* (cls_stride / box_stride: elements between the rows of cls_logits / box_raw - views of vector-padded MLP outputs; 0 = dense) */
 int sihl_od_anchors(const int* level_hw, int n_levels, float* offsets, float* scales, hipStream_t stream);
 
 /* ---- InstanceSegmentation mask decode (heads/instance_segmentation.py:121-163) -----------

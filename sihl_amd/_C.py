@@ -85,7 +85,7 @@ SIGNATURES = {
     "sihl_topk_select_enable": (I, [I]),
     "sihl_topk_rows": (I, [P, I, I, I, I, P, P, I, P]),
     "sihl_gather_rows": (I, [P, P, P, I, I, I, I, I, P]),
-    "sihl_od_decode": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, I, P]),
+    "sihl_od_decode": (I, [P, P, P, L, P, L, P, I, I, I, I, I, I, P, P, P, P, I, P]),
     "sihl_od_anchors": (I, [P, I, P, P, P]),
     "sihl_iseg_mask_decode": (I, [P, P, L, P, P, I, I, I, I, I, I, I, P, I, P]),
     "sihl_uafm_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P]),

@@ -169,39 +169,65 @@ __global__ void gather_rows_kernel(const T* __restrict__ src, const int* __restr
 struct Levels { int n; int h[8]; int w[8]; };
 
 // scores = sigmoid(topk logits); classes = argmax_c cls_logits; boxes = (offsets + scales*exp(box))*full
-// num_instances[b] = #(scores > 0.5).  One thread per (b, k).
+// num_instances[b] = #(scores > 0.5).  One workgroup per image; 8 lanes share an instance: each takes every eighth
+// class of the argmax (the first maximum wins, as torch.max: ties go to the smaller class index) and lane 0 decodes the box;
+// the count is a wave ballot + one LDS add per wave (no atomics on global memory, no memset in front).
+// cls_logits / box_raw: rows cls_stride / box_stride elements apart (views of vector-padded MLP outputs).
 template <typename T>
-__global__ void od_decode_kernel(const float* __restrict__ top_vals, const int* __restrict__ top_idx,
-                                 const T* __restrict__ cls_logits, const T* __restrict__ box_raw, Levels lv, int B,
-                                 int K, int ncls, float full_w, float full_h, float* __restrict__ scores,
-                                 long* __restrict__ classes, float* __restrict__ boxes, long* __restrict__ num_inst) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * K) return;
-  const int b = i / K;
-  const float s = 1.f / (1.f + expf(-top_vals[i]));
-  scores[i] = s;
-  if (s > 0.5f) atomicAdd((unsigned long long*)(num_inst + b), 1ULL);
-  // argmax (first maximum wins, as torch.max)
-  const T* cl = cls_logits + (long)i * ncls;
-  float best = elem<T>::ld(cl);
-  int arg = 0;
-  for (int c = 1; c < ncls; ++c) {
-    const float v = elem<T>::ld(cl + c);
-    if (v > best) { best = v; arg = c; }
+__global__ __launch_bounds__(256) void od_decode_kernel(const float* __restrict__ top_vals, const int* __restrict__ top_idx,
+                                                        const T* __restrict__ cls_logits, long cls_stride,
+                                                        const T* __restrict__ box_raw, long box_stride, Levels lv, int K, int ncls,
+                                                        float full_w, float full_h, float* __restrict__ scores,
+                                                        long* __restrict__ classes, float* __restrict__ boxes,
+                                                        long* __restrict__ num_inst) {
+  __shared__ int count;
+  const int b = blockIdx.x, sub = threadIdx.x & 7;
+  if (threadIdx.x == 0) count = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    const int k = k0 + (threadIdx.x >> 3);
+    const bool ok = k < K;
+    const long i = (long)b * K + (ok ? k : 0);
+    const T* cl = cls_logits + i * cls_stride;
+    float best = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int c = sub; c < ncls; c += 8) {
+      const float v = elem<T>::ld(cl + c);
+      if (v > best || (v != v && best == best)) { best = v; arg = c; }  // NaN wins, as torch.max
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      const float ob = __shfl_xor(best, o);
+      const int oa = __shfl_xor(arg, o);
+      const bool take = (ob > best) || (ob != ob && best == best) || (ob == best && oa < arg) || (ob != ob && best != best && oa < arg);
+      if (take) { best = ob; arg = oa; }
+    }
+    if (ok && sub == 0) {
+      const float s = 1.f / (1.f + expf(-top_vals[i]));
+      scores[i] = s;
+      mine += s > 0.5f ? 1 : 0;
+      classes[i] = arg;
+      // position index -> level, cell
+      int p = top_idx[i], l = 0;
+      while (l < lv.n - 1 && p >= lv.h[l] * lv.w[l]) { p -= lv.h[l] * lv.w[l]; ++l; }
+      const int h = lv.h[l], w = lv.w[l];
+      const int cy = p / w, cx = p - cy * w;
+      const float hx = 0.5f / w, hy = 0.5f / h;
+      const float ox = (cx + 0.5f) / w, oy = (cy + 0.5f) / h;
+      const T* br = box_raw + i * box_stride;
+      float4 o;
+      o.x = (ox - hx * expf(elem<T>::ld(br + 0))) * full_w;
+      o.y = (oy - hy * expf(elem<T>::ld(br + 1))) * full_h;
+      o.z = (ox + hx * expf(elem<T>::ld(br + 2))) * full_w;
+      o.w = (oy + hy * expf(elem<T>::ld(br + 3))) * full_h;
+      *(float4*)(boxes + i * 4) = o;
+    }
   }
-  classes[i] = arg;
-  // position index -> level, cell
-  int p = top_idx[i], l = 0;
-  while (l < lv.n - 1 && p >= lv.h[l] * lv.w[l]) { p -= lv.h[l] * lv.w[l]; ++l; }
-  const int h = lv.h[l], w = lv.w[l];
-  const int cy = p / w, cx = p - cy * w;
-  const float hx = 0.5f / w, hy = 0.5f / h;
-  const float ox = (cx + 0.5f) / w, oy = (cy + 0.5f) / h;
-  const T* br = box_raw + (long)i * 4;
-  boxes[(long)i * 4 + 0] = (ox - hx * expf(elem<T>::ld(br + 0))) * full_w;
-  boxes[(long)i * 4 + 1] = (oy - hy * expf(elem<T>::ld(br + 1))) * full_h;
-  boxes[(long)i * 4 + 2] = (ox + hx * expf(elem<T>::ld(br + 2))) * full_w;
-  boxes[(long)i * 4 + 3] = (oy + hy * expf(elem<T>::ld(br + 3))) * full_h;
+  mine = (int)wave_sum((float)mine);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&count, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) num_inst[b] = count;
 }
 
 // ------------------------------------------------------------------ CondInst mask decode (instance segmentation)
@@ -559,23 +585,24 @@ int sihl_gather_rows(const void* src, const int* idx, void* out, int B, int P, i
   return SIHL_OK;
 }
 
-// level_hw: host array [n_levels][2] = (h, w) of each pyramid level, bottom first.
-int sihl_od_decode(const float* top_vals, const int* top_idx, const void* cls_logits, const void* box_raw,
-                   const int* level_hw, int n_levels, int B, int K, int ncls, int full_w, int full_h, float* scores,
-                   long* classes, float* boxes, long* num_instances, int dtype, hipStream_t stream) {
+// level_hw: host array [n_levels][2] = (h, w) of each pyramid level, bottom first.  cls_logits [B*K] rows of ncls values
+// cls_stride elements apart, box_raw [B*K] rows of 4 values box_stride elements apart (0 = dense).
+int sihl_od_decode(const float* top_vals, const int* top_idx, const void* cls_logits, long cls_stride, const void* box_raw,
+                   long box_stride, const int* level_hw, int n_levels, int B, int K, int ncls, int full_w, int full_h,
+                   float* scores, long* classes, float* boxes, long* num_instances, int dtype, hipStream_t stream) {
   if (!top_vals || !top_idx || !cls_logits || !box_raw || !level_hw || n_levels <= 0 || n_levels > 8 || B <= 0 ||
       K <= 0 || ncls <= 0 || !scores || !classes || !boxes || !num_instances)
     return SIHL_EARG;
+  if (cls_stride == 0) cls_stride = ncls;
+  if (box_stride == 0) box_stride = 4;
+  if (cls_stride < ncls || box_stride < 4) return SIHL_EARG;
   Levels lv;
   lv.n = n_levels;
   for (int i = 0; i < n_levels; ++i) { lv.h[i] = level_hw[2 * i]; lv.w[i] = level_hw[2 * i + 1]; }
-  hipError_t e = hipMemsetAsync(num_instances, 0, (size_t)B * sizeof(long), stream);
-  if (e != hipSuccess) return (int)e;
-  const int g = (B * K + 255) / 256;
   if (dtype == SIHL_F32)
-    hipLaunchKernelGGL(od_decode_kernel<float>, dim3(g), dim3(256), 0, stream, top_vals, top_idx, (const float*)cls_logits, (const float*)box_raw, lv, B, K, ncls, (float)full_w, (float)full_h, scores, classes, boxes, num_instances);
+    hipLaunchKernelGGL(od_decode_kernel<float>, dim3(B), dim3(256), 0, stream, top_vals, top_idx, (const float*)cls_logits, cls_stride, (const float*)box_raw, box_stride, lv, K, ncls, (float)full_w, (float)full_h, scores, classes, boxes, num_instances);
   else if (dtype == SIHL_BF16)
-    hipLaunchKernelGGL(od_decode_kernel<bf16_t>, dim3(g), dim3(256), 0, stream, top_vals, top_idx, (const bf16_t*)cls_logits, (const bf16_t*)box_raw, lv, B, K, ncls, (float)full_w, (float)full_h, scores, classes, boxes, num_instances);
+    hipLaunchKernelGGL(od_decode_kernel<bf16_t>, dim3(B), dim3(256), 0, stream, top_vals, top_idx, (const bf16_t*)cls_logits, cls_stride, (const bf16_t*)box_raw, box_stride, lv, K, ncls, (float)full_w, (float)full_h, scores, classes, boxes, num_instances);
   else return SIHL_EARG;
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;

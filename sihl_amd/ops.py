@@ -1222,10 +1222,14 @@ def od_decode(top_vals, top_idx, cls_logits, box_raw, level_hw, full_wh):
     classes = torch.empty((B, K), dtype=torch.int64, device=dev)
     boxes = torch.empty((B, K, 4), dtype=torch.float32, device=dev)
     num = torch.empty((B,), dtype=torch.int64, device=dev)
-    cls_logits, box_raw = cls_logits.contiguous(), box_raw.contiguous()
-    rc = _C.lib().sihl_od_decode(_p(top_vals), _p(top_idx), _p(cls_logits), _p(box_raw), _levels_arr(level_hw),
-                                 len(level_hw), B, K, ncls, int(full_wh[0]), int(full_wh[1]), _p(scores),
-                                 _p(classes), _p(boxes), _p(num), _dt(cls_logits), _stream())
+    # (B, K, n) views of vector-padded MLP outputs are read through their row stride: no compaction copy
+    def rows(t):
+        t2 = t.reshape(B * K, t.shape[-1]) if t.dim() != 2 else t
+        return t2 if t2.stride(1) == 1 else t2.contiguous()
+    cls_logits, box_raw = rows(cls_logits), rows(box_raw)
+    rc = _C.lib().sihl_od_decode(_p(top_vals), _p(top_idx), _p(cls_logits), cls_logits.stride(0), _p(box_raw),
+                                 box_raw.stride(0), _levels_arr(level_hw), len(level_hw), B, K, ncls, int(full_wh[0]),
+                                 int(full_wh[1]), _p(scores), _p(classes), _p(boxes), _p(num), _dt(cls_logits), _stream())
     check(rc, "sihl_od_decode")
     return num, scores, classes, boxes
 
