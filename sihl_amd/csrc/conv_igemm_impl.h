@@ -1057,9 +1057,13 @@ int dispatch(const ConvParams& p, hipStream_t stream) {
         return launch_n128<T>(p, stream);
       if (g_tile_override == 256 || (g_tile_override == 0 && p.M >= 256 * 256)) return launch_dma<T, 256, 256, 4, 2>(p, stream);
     }
-    if constexpr (sizeof(T) == 2) {  // tuning: 128 pixels x 256 channels on 8 waves (2 x 4), 2 / 3 LDS stages
+    if constexpr (sizeof(T) == 2) {  // 128 pixels x 256 channels on 8 waves (2 x 4), 2 / 3 LDS stages
       if (g_tile_override == 2562) return launch_dma<T, 128, 256, 2, 4, 2>(p, stream);
       if (g_tile_override == 2563) return launch_dma<T, 128, 256, 2, 4, 3>(p, stream);
+      // windowed convs over 16 k - 64 k pixels into 256 channels (P4 3x3 at batch 32: 256 workgroups, one per CU, the
+      // whole weight panel width per workgroup): 46 us against 52 for 512 single-stage 128x128 tiles (tools/tile_probe.py)
+      if (g_tile_override == 0 && !(g_rules_off & 8) && p.KH * p.KW > 1 && p.Cout == 256 && tiles128 >= 128 && tiles128 <= 384)
+        return launch_dma<T, 128, 256, 2, 4, 2>(p, stream);
     }
     if (g_tile_override == 64 || (g_tile_override == 0 && tiles128 * ((p.Cout + 255) / 256) <= 64))
       return launch_n64<T>(p, stream);
