@@ -105,6 +105,35 @@ def cpu_baseline(sample_batch, size, iters=5, warm=2):
                       f"workload, median of {iters} steps after {warm} warm-ups ({dt:.2f} s/step)"}
 
 
+def north_star_cpu_baseline(sample_batch, size, iters=5, warm=2):
+    """The north-star sub-metric on the host cores: the oracle's BiFPN(3-7) + ObjectDetection.forward (the CPU restatement of
+    reference layers/bifpn.py:89-97 + heads/object_detection.py:99-122), eval, fp32, on the same seeded level list at a
+    bounded batch (images are independent); median of `iters` forwards after `warm` warm-ups."""
+    import oracle
+
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    chans = [3, 64, 256, 512, 1024, 2048]
+    torch.manual_seed(0)
+    neck = oracle.BiFPN(chans, 256, 3, 7).eval()
+    head = oracle.ObjectDetection(neck.out_channels, 80, 3, 7).eval()
+    g = torch.Generator().manual_seed(1)
+    levels = [torch.zeros(sample_batch, 3, size, size)] + [
+        torch.randn(sample_batch, c, size // 2 ** l, size // 2 ** l, generator=g).contiguous(memory_format=torch.channels_last)
+        for l, c in enumerate(chans) if l > 0]
+    times = []
+    with torch.no_grad():
+        for i in range(warm + iters):
+            t0 = time.perf_counter()
+            head(neck(levels))
+            if i >= warm:
+                times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]
+    return {"value": sample_batch / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle BiFPN + ObjectDetection.forward (CPU fp32), bs={sample_batch} of the same {size}x{size} level "
+                      f"list, median of {iters} forwards after {warm} warm-ups ({dt:.2f} s/forward)"}
+
+
 def source_stamp():
     """sha256 over the kernel sources: profiles/*pmc*.json carry it, so a traffic figure measured on other code is
     recognisably stale."""
@@ -439,6 +468,20 @@ def main():
         dist.all_reduce(seen)
     dt = float(t.item())
     ranks_seen = int(seen.item())
+    # per-rank host issue time and the time the step's stream stood still for the all-reduces: a poor 1 -> N curve is then
+    # attributable (host-bound ranks / exposed collectives) from this one line
+    dp_stats = None
+    if world > 1:
+        wait_ms = trainer.averager.wait_ms() if trainer.averager.active else 0.0
+        v = torch.tensor([t_enqueued / args.steps * 1e3, wait_ms], device=device, dtype=torch.float64)
+        vmax, vsum = v.clone(), v.clone()
+        dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(vsum)
+        dp_stats = {"host_issue_ms_per_step_max": float(vmax[0]), "host_issue_ms_per_step_mean": float(vsum[0]) / world,
+                    "allreduce_wait_ms_per_step_max": float(vmax[1]), "allreduce_wait_ms_per_step_mean": float(vsum[1]) / world,
+                    "gradient_buckets": len(trainer.averager.buckets),
+                    "what": "host time to enqueue a step; time the step's stream waited in GradientAverager.finish() for "
+                            "the bucketed all-reduces (the part backward did not hide), mean of the timed steps per rank"}
 
     # roofline of the dominant kernel: matrix-core conv (forward / dgrad / linear launches)
     dt_code = _C.BF16 if args.dtype == "bf16" else _C.F32
@@ -515,6 +558,8 @@ def main():
                        "final_loss": final_loss},
             "roofline": roofline,
         }
+        if dp_stats is not None:
+            out["data_parallel"] = dp_stats
         if fwd is not None:
             out["north_star_forward"] = fwd
         if sub is not None:
@@ -529,6 +574,10 @@ def main():
         out["source_stamp"] = source_stamp()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.size)
+            if "north_star_forward" in out and args.size == 512:
+                out["north_star_forward"]["cpu_baseline"] = north_star_cpu_baseline(args.cpu_sample, args.size)
+                out["north_star_forward"]["vs_cpu_baseline"] = out["north_star_forward"]["images_per_s"] / \
+                    out["north_star_forward"]["cpu_baseline"]["value"]
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     if world > 1:

@@ -62,6 +62,7 @@ class GradientAverager:
         self.params = [p for p in params if p.requires_grad]
         self.buckets: List[Dict[str, Any]] = []
         self.where: Dict[int, Any] = {}
+        self._waits: List[Any] = []
         self.active = self.world > 1 or (force and dist.is_initialized())
         if not self.active:
             return
@@ -126,14 +127,32 @@ class GradientAverager:
         if b["pending"] == 0:  # every gradient of the bucket is final: pack it and start its all-reduce
             self._launch(b)
 
+    def wait_ms(self) -> float:
+        """Mean time per step (over the last <= 64) that the step's stream waited in ``finish()`` for the all-reduces to
+        complete - the part of the exchange that backward did not hide.  Synchronises the device."""
+        if not self._waits:
+            return 0.0
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self._waits) / len(self._waits)
+
     def finish(self) -> None:
         if not self.active:
             return
         for b in self.buckets:
             if b["work"] is None:  # some parameter of this bucket got no gradient this step
                 self._launch(b)
+        timed = self.buckets[0]["flat"].is_cuda
+        if timed:  # how long the step's stream stands still for the collectives (read back lazily: wait_ms())
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         for b in self.buckets:
             b["work"].wait()
+        if timed:
+            ev1.record()
+            self._waits.append((ev0, ev1))
+            if len(self._waits) > 64:
+                del self._waits[:-64]
+        for b in self.buckets:
             if not self.use_avg:
                 b["flat"].div_(self.world)
             pairs = [(p.grad, v) for p, v in zip(b["params"], b["views"]) if p.grad is not None]
