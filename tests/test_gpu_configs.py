@@ -1,5 +1,6 @@
 """BASELINE.json configurations that are not the benchmark line, as parity / property tests:
-  configs[1]  ResNet50 + FPN(3-5) + SemanticSegmentation, 3x512x512, fp32 (batch 2 for the oracle leg; bs 16 in the config)
+  configs[1]  ResNet50 + FPN(3-5) + SemanticSegmentation (93 classes), 3x512x512, fp32 (batch 8 for the oracle leg, the
+              configuration's batch 16 as a HIP-only training step; end-to-end tolerance derived from the head's conditioning)
   configs[4]  convnext_base-shaped TimmBackbone ([3, 3, 128, 256, 512, 1024] with the reference's fake level 1,
               timm_backbone.py:143-152) + BiFPN(3-7) + {ObjectDetection, SemanticSegmentation}, 3x640x640:
               fp32 small-batch parity against the oracle, bf16 batch-16 properties (P = 8525 positions)."""
@@ -44,11 +45,12 @@ def test_config2_resnet50_fpn_semseg_512_fp32_matches_oracle():
     torch.manual_seed(0)
     o_bb = oracle.ResNetBackbone("resnet50", top_level=5)
     o_neck = oracle.FPN(o_bb.out_channels, 256, 3, 5)
-    o_head = oracle.SemanticSegmentation(o_neck.out_channels, num_classes=21, bottom_level=3, top_level=5)
+    NCLS = 93  # the example's class count (BASELINE configs[1]; examples/semantic_segmentation.py)
+    o_head = oracle.SemanticSegmentation(o_neck.out_channels, num_classes=NCLS, bottom_level=3, top_level=5)
     o_model = oracle.SihlModel(o_bb, o_neck, [o_head])
     h_bb = sihl_amd.ResNetBackbone("resnet50", top_level=5)
     h_neck = sihl_amd.layers.FPN(h_bb.out_channels, 256, 3, 5)
-    h_head = sihl_amd.heads.SemanticSegmentation(h_neck.out_channels, num_classes=21, bottom_level=3, top_level=5)
+    h_head = sihl_amd.heads.SemanticSegmentation(h_neck.out_channels, num_classes=NCLS, bottom_level=3, top_level=5)
     h_model = sihl_amd.SihlModel(h_bb, h_neck, [h_head])
     h_model.load_state_dict(o_model.state_dict(), strict=True)
     h_model = h_model.cuda().to(memory_format=torch.channels_last)
@@ -57,7 +59,7 @@ def test_config2_resnet50_fpn_semseg_512_fp32_matches_oracle():
     g = torch.Generator().manual_seed(5)
     B = 8
     x = torch.rand(B, 3, 512, 512, generator=g)
-    target = torch.randint(0, 21, (B, 512, 512), generator=g)
+    target = torch.randint(0, NCLS, (B, 512, 512), generator=g)
     o_model.train(), h_model.train()
 
     def run(model, dev, feats=None):
@@ -81,9 +83,34 @@ def test_config2_resnet50_fpn_semseg_512_fp32_matches_oracle():
     _, head_ref_logits, head_ref_loss = run(o_model, "cpu", feats=[f.float().cpu() for f in hip_f])
     _close(hip_logits, head_ref_logits, 1e-4, "logits (same features)")
     _close(hip_loss, head_ref_loss, 1e-4, "loss (same features)")
-    # (c) end to end: within the head's measured amplification (30x) of the feature tolerance
-    _close(hip_logits, ref_logits, 3e-3, "logits (end to end)")
-    _close(hip_loss, ref_loss, 1e-3, "loss (end to end)")
+    # (c) end to end.  The tolerance is DERIVED here, not chosen: the reference's own head (the oracle, on the CPU) is run
+    # once more on its own features with uniform noise of relative size 1e-4 injected at the neck output; the movement of
+    # its logits / loss per unit of feature noise is the head's conditioning kappa on THIS input, and the end-to-end
+    # deviation of the HIP path must stay within kappa x the feature deviation measured in (a) (x3: structured rounding
+    # differences of a conv stack are not uniform noise) plus the head's own 1e-4 of (b).
+    noise = 1e-4
+    gn = torch.Generator().manual_seed(9)
+    noisy = [f if l < 3 else f + noise * max(1.0, float(f.abs().max())) * (2 * torch.rand(f.shape, generator=gn) - 1)
+             for l, f in enumerate(ref_f)]
+    _, noisy_logits, noisy_loss = run(o_model, "cpu", feats=noisy)
+    rel = lambda a, b: float((a.float().cpu() - b.float().cpu()).abs().max()) / max(1.0, float(b.abs().max()))  # noqa: E731
+    kappa_logits, kappa_loss = rel(noisy_logits, ref_logits) / noise, rel(noisy_loss, ref_loss) / noise
+    feat_err = max(rel(hip_f[l], ref_f[l]) for l in range(3, 6))
+    e_logits, e_loss = rel(hip_logits, ref_logits), rel(hip_loss, ref_loss)
+    print(f"config 2: feature deviation {feat_err:.2e}; head conditioning (logits / loss) {kappa_logits:.1f} / {kappa_loss:.1f}; "
+          f"end-to-end deviation {e_logits:.2e} / {e_loss:.2e}")
+    assert feat_err <= 2e-4
+    assert e_logits <= 3 * kappa_logits * feat_err + 1e-4, (e_logits, kappa_logits, feat_err)
+    assert e_loss <= 3 * kappa_loss * feat_err + 1e-4, (e_loss, kappa_loss, feat_err)
+    assert e_logits <= 1e-2 and e_loss <= 1e-2  # and a hard backstop whatever the conditioning
+    # the configuration's own batch (16) through the HIP path alone: one training step with finite loss and gradients
+    x16 = torch.rand(16, 3, 512, 512, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    t16 = torch.randint(0, NCLS, (16, 512, 512), generator=g).cuda()
+    loss16, _ = h_model.heads[0].training_step(h_model.extract_features(x16), t16)
+    loss16.backward()
+    assert torch.isfinite(loss16) and 0.5 * float(torch.log(torch.tensor(float(NCLS)))) < float(loss16) < 3 * float(torch.log(torch.tensor(float(NCLS))))
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in h_model.parameters() if p.requires_grad)
+    h_model.zero_grad(set_to_none=True)
     # eval forward: (scores, classes) at input resolution; classes are integers and must agree wherever the two best
     # logits are not within rounding of each other
     h_model.load_state_dict(o_model.state_dict(), strict=True)  # identical running statistics for the eval pass
@@ -161,7 +188,9 @@ def test_config5_multitask_bf16_batch16_properties():
     from sihl_amd.train import Trainer
 
     torch.manual_seed(0)
-    model = _config5(sihl_amd.TimmBackbone, sihl_amd.layers, sihl_amd.heads, sihl_amd.SihlModel, (1, 1, 2, 1))
+    # the configuration's real trunk depth: convnext_base = (3, 3, 27, 3) blocks (timm_backbone.py:119-126)
+    model = _config5(sihl_amd.TimmBackbone, sihl_amd.layers, sihl_amd.heads, sihl_amd.SihlModel, (3, 3, 27, 3))
+    assert sum(p.numel() for p in model.backbone.parameters()) > 80e6  # ~88 M parameters: the base model, not a stand-in
     model = model.cuda().to(memory_format=torch.channels_last)
     x = torch.rand(16, 3, 640, 640, generator=torch.Generator().manual_seed(2)).cuda()
     x = x.contiguous(memory_format=torch.channels_last)

@@ -106,7 +106,8 @@ def test_hip_bf16_deep(name):
             whose true gradient is zero (a bias in front of a norm);
     hip   = the bf16 kernels.
     Every floating result - all gradients, however small the tensor - must lie within 3x its floor + 3 % of its
-    norm; forward outputs and losses additionally within 3e-2 of their magnitude (or twice their own worst-element
+    norm (and, where the floor itself lies between 0.3 and 1, with a cosine of at least 0.3 against the reference);
+    forward outputs and losses additionally within 3e-2 of their magnitude (or twice their own worst-element
     floor where that is larger: the HybridEncoder's deepest level).  (profiles/r02_bf16_floor.txt has the
     measured table.)"""
     import oracle.heads
@@ -123,6 +124,18 @@ def test_hip_bf16_deep(name):
         err = float((res[k].float() - g.float()).norm() / g.float().norm().clamp(min=1e-30))
         if err > 3 * floor[k] + 3e-2:
             bad.append(f"{k} (n={g.numel()}): hip {err:.3e} vs floor {floor[k]:.3e}")
+        # Backstop where the floor is so high that "3 x floor" could hardly fail (fusion-weight and norm-bias gradients of
+        # the deep stacks: differences of large dot products, floor 0.3 - 0.9): the gradient must at least point the same way
+        # as the reference's (cosine >= 0.3; measured 0.55 - 0.99, the lowest on the 1x1-pooled BatchNorm branch of the
+        # DepthEstimation decoder, whose magnitude bf16 rounding alone moves by 65 %).  Above a floor of 1 bf16's own rounding noise exceeds the signal
+        # - the emulated bf16 oracle itself flips the sign of gp.layers.1.up_fusions.1.weights (floor 2.4; its two softmax
+        # components are +-a with a the difference of two large sums) and tensors whose TRUE gradient is zero (a bias in
+        # front of a norm) reach 1e4: no direction exists to compare with, the 3 x floor rule bounds their magnitude.
+        if 0.3 < floor[k] < 1.0:
+            a, b = res[k].float().flatten().cpu(), g.float().flatten().cpu()
+            cos = float(torch.dot(a, b) / (a.norm() * b.norm()).clamp(min=1e-30))
+            if cos < 0.3:
+                bad.append(f"{k} (n={g.numel()}): hip {err:.3e}, cosine {cos:.3f} against the reference (floor {floor[k]:.3e})")
         if not k.startswith("g"):
             lim = max(3e-2, 2 * floor[k + "|max"])
             assert _rel2max(res[k], g) < lim, f"{name}:{k}: {_rel2max(res[k], g):.3e} (limit {lim:.3e})"
