@@ -280,9 +280,6 @@ def main():
     ap.add_argument("--graph-warmup-stream", default="off", choices=["off", "small", "all"],
                     help="debugging only, with --graph: stream mode of the eager warm-up steps before the capture (the "
                          "round-1 fault needed 'all'; a graph Trainer otherwise never uses a second stream)")
-    ap.add_argument("--unsafe-queue-replays", action="store_true",
-                    help="diagnostic only, with --graph --graph-warmup-stream all: drop the Trainer's one-replay-in-flight "
-                         "rule for this process (the round-1 fault configuration)")
     ap.add_argument("--memory-map", default="",
                     help="diagnostic only: write allocator segments + named tensors (tools/graph_fault_map.py) to this "
                          "file right before the timed steps")
@@ -397,9 +394,6 @@ def main():
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
         from graph_fault_map import take_snapshot
         take_snapshot(model, trainer, {}, "before the timed steps", args.memory_map)
-    if args.unsafe_queue_replays:
-        from sihl_amd import ops as _ops
-        _ops.side_stream_history = lambda: False
     allocs0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):

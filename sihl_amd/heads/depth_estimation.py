@@ -69,12 +69,14 @@ class DepthEstimation(SemanticSegmentation):
         pred_shape = depth.shape[2:]
         depth = F.interpolate(depth, size=targets.shape[2:])
         g = (depth[masks] + EPS).log() - (targets[masks] + EPS).log()
-        pix_loss = torch.sqrt(g.var() + 0.15 * g.mean().pow(2)) * 10
+        gm = g.mean()
+        pix_loss = torch.sqrt(g.var() + 0.15 * gm * gm) * 10
         masks = F.interpolate(masks.to(torch.uint8), size=pred_shape, mode="nearest") > 0
         targets = F.interpolate(targets, size=pred_shape)
         hist = []
         for b in range(B):
-            dist = (centers[b][None, :] - targets[b][masks[b]][:, None]).pow(2)
+            dist = centers[b][None, :] - targets[b][masks[b]][:, None]
+            dist = dist * dist
             hist.append(dist.min(dim=1).values.mean() + dist.min(dim=0).values.mean())
         hist_loss = torch.stack(hist).mean()
         return pix_loss + hist_loss, {"pixel_loss": pix_loss, "hist_loss": hist_loss}

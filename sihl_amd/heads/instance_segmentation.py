@@ -164,7 +164,7 @@ class InstanceSegmentation(nn.Module):
         target = torch.cat(masks).to(preds)[flat_gt]
         target = F.interpolate(target.unsqueeze(1), size=preds.shape[1:], mode="bilinear").squeeze(1)
         num = (preds * target).sum((1, 2))
-        den = (preds ** 2 + target ** 2).sum((1, 2))
+        den = (preds * preds + target * target).sum((1, 2))
         mask_loss = 1 - 2 * num.float() / den
         mask_loss = (wts * mask_loss).sum() / wts.sum()
 

@@ -25,7 +25,9 @@ def sigmoid_focal_loss(logits: Tensor, targets: Tensor, alpha: float = 0.25, gam
     p = torch.sigmoid(logits)
     ce = F.binary_cross_entropy_with_logits(logits, targets, reduction="none")
     p_t = p * targets + (1 - p) * (1 - targets)
-    return (alpha * targets + (1 - alpha) * (1 - targets)) * ce * (1 - p_t) ** gamma
+    q = 1 - p_t
+    mod = q * q if gamma == 2.0 else q ** gamma  # (x * x, not pow(x, 2): no clone node in a captured backward - box_ops.sq)
+    return (alpha * targets + (1 - alpha) * (1 - targets)) * ce * mod
 
 
 class QuadrilateralDetection(nn.Module):

@@ -336,7 +336,10 @@ class Trainer:
         prematched_on = self._prematch(images, targets)
         if self.autocast_dtype is not None:
             # the backbone runs under autocast (ATen / MIOpen); the neck and heads take its bf16 level list
-            with torch.autocast(device_type=dev_type, dtype=self.autocast_dtype):
+            # (no autocast weight-cast cache inside a graph capture: its entries would be tensors of the graph's private pool
+            # outliving the capture - torch's own graph helpers capture with cache_enabled=False too)
+            capturing = images.is_cuda and torch.cuda.is_current_stream_capturing()
+            with torch.autocast(device_type=dev_type, dtype=self.autocast_dtype, cache_enabled=not capturing):
                 levels = self.model.backbone(images)
             levels = [t if i == 0 else t.to(self.autocast_dtype) for i, t in enumerate(levels)]
             feats = self.model.neck(levels) if self.model.neck is not None else levels
