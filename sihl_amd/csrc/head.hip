@@ -396,7 +396,11 @@ __device__ __forceinline__ float gmax_w(float a, float b) { return a > b ? 1.f :
 template <typename T>
 __global__ __launch_bounds__(256) void od_loss_kernel(const OdLossArgs a) {
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-  const float keep = *a.none_matched ? 0.f : 1.f;  // degenerate ground truths only: the total is the location loss
+  const bool nm = *a.none_matched;
+  const float keep = nm ? 0.f : 1.f;  // degenerate ground truths only: the total is the location loss
+  // (then wsum and iou_norm are 0 as well: the reciprocals are taken as 0 instead, so the gradients of the three unused
+  // terms are exact zeros rather than 0 * inf)
+  const float inv_iou_norm = nm ? 0.f : 1.f / *a.iou_norm;
   float s_loc = 0.f, s_iou = 0.f, s_box = 0.f, s_cls = 0.f;
   if (gid < a.N1) {
     const float x = elem<T>::ld((const T*)a.loc + gid), t = a.loc_target[gid];
@@ -404,11 +408,11 @@ __global__ __launch_bounds__(256) void od_loss_kernel(const OdLossArgs a) {
     elem<T>::st((T*)a.d_loc + gid, (1.f / (1.f + expf(-x)) - t) / *a.loc_norm);
     const float q = elem<T>::ld((const T*)a.iou + gid), r = a.rel_iou[gid], d = q - r;
     s_iou = d * d;
-    elem<T>::st((T*)a.d_iou + gid, keep * 2.f * d / *a.iou_norm);
+    elem<T>::st((T*)a.d_iou + gid, keep * 2.f * d * inv_iou_norm);
   }
   if (gid < a.R) {
     const int r = (int)gid;
-    const float w = a.wts[r], inv_wsum = 1.f / *a.wsum;
+    const float w = a.wts[r], inv_wsum = nm ? 0.f : 1.f / *a.wsum;
     // ---- box: pred = off + scale * exp(raw)
     float raw[4], e[4], b[4], g[4];
 #pragma unroll
@@ -457,7 +461,9 @@ __global__ __launch_bounds__(256) void od_loss_kernel(const OdLossArgs a) {
       const float duni = darea[k] - dint[k];
       const float diou = (dint[k] * ue - inter * duni) / (ue * ue);
       const float dL = -diou + (drho[k] * c2 - rho2 * dc2[k]) / (c2 * c2) + alpha * dv[k];
-      elem<T>::st((T*)a.d_box + r * 4 + k, scale * dL * a.cand_scale[r * 4 + k] * e[k]);
+      // (a zero-weight row - padding, or every row when nothing matched - gets an exact zero: a degenerate target box
+      // makes dL infinite or NaN, and 0 * that is NaN)
+      elem<T>::st((T*)a.d_box + r * 4 + k, scale == 0.f ? 0.f : scale * dL * a.cand_scale[r * 4 + k] * e[k]);
     }
     // ---- class: cross-entropy over C logits
     const T* lg = (const T*)a.cls + (long)r * a.C;
@@ -470,7 +476,7 @@ __global__ __launch_bounds__(256) void od_loss_kernel(const OdLossArgs a) {
     s_cls = w * (lse - elem<T>::ld(lg + tc));
     const float cs = keep * w * inv_wsum, iz = 1.f / z;
     T* dl = (T*)a.d_cls + (long)r * a.C;
-    for (int c = 0; c < a.C; ++c) elem<T>::st(dl + c, cs * (expf(elem<T>::ld(lg + c) - m) * iz - (c == tc ? 1.f : 0.f)));
+    for (int c = 0; c < a.C; ++c) elem<T>::st(dl + c, cs == 0.f ? 0.f : cs * (expf(elem<T>::ld(lg + c) - m) * iz - (c == tc ? 1.f : 0.f)));
   }
   // block sums (fixed order inside the block; blocks are summed in order by the finalize kernel)
   __shared__ float red[4][4];

@@ -97,10 +97,10 @@ def workspace(nbytes: int, device) -> Tensor:
 # side stream reads, so they are held alive until the join (the caching allocator would otherwise hand their blocks
 # to later main-stream kernels while the wgrad is still queued).
 class _Side:
-    __slots__ = ("stream", "holds", "mode", "dirty")
+    __slots__ = ("stream", "holds", "mode", "dirty", "seen")
 
     def __init__(self, stream, mode):
-        self.stream, self.holds, self.mode, self.dirty = stream, [], mode, False
+        self.stream, self.holds, self.mode, self.dirty, self.seen = stream, [], mode, False, set()
 
 
 _SIDE: Optional[_Side] = None
@@ -157,6 +157,20 @@ class wgrad_side_stream:
         return False
 
 
+def _guard_shared_parameters(keys) -> None:
+    """A parameter used MORE THAN ONCE in one backward (a module called twice per step): autograd then adds its gradients -
+    a kernel on the main stream - and must not start before the side stream has written them.  `keys`: storage addresses
+    of the parameters whose gradients this backward node has just queued on the side stream; from a parameter's second
+    appearance on, the main stream waits for the side stream before the node returns.  (A parameter used once is handed to
+    AccumulateGrad as it is, no kernel: no wait - the common case costs a set lookup.)"""
+    side = _SIDE
+    if side is None or not side.dirty:
+        return
+    if any(k in side.seen for k in keys):
+        torch.cuda.current_stream().wait_stream(side.stream)
+    side.seen.update(keys)
+
+
 def side_stream_history() -> bool:
     """True once any side stream has been created in this process (eager two-stream steps have run)."""
     return bool(_SIDE_STREAMS)
@@ -183,6 +197,7 @@ def join_side_stream() -> None:
         torch.cuda.current_stream().wait_stream(_SIDE.stream)
         _SIDE.holds = []
         _SIDE.dirty = False
+        _SIDE.seen = set()
 
 
 def nhwc(x: Tensor) -> Tensor:
@@ -544,6 +559,7 @@ class ConvBlockFn(torch.autograd.Function):
         KH, KW = w.shape[1], w.shape[2]
         ctx.cfg, ctx.has_norm, ctx.kshape = cfg, has_norm, (KH, KW)
         ctx.has_bias = bias is not None
+        ctx.pkeys = (weight.data_ptr(),) + ((bias.data_ptr(),) if bias is not None else ())
         if not has_norm:
             fused_ok = act in (None, "none", "relu")
             if fused_ok or not need_grad:
@@ -656,6 +672,7 @@ class ConvBlockFn(torch.autograd.Function):
                                            stride, pad, dil, _dt(x), _p(ws), ws.numel() if ws is not None else 0,
                                            _stream())
             check(rc, "sihl_conv2d_dgrad")
+        _guard_shared_parameters(ctx.pkeys)
         return dx, dw, dbias, dgamma, dbeta, None, None, None, dres, None, None, None
 
 
@@ -958,6 +975,7 @@ class LinearFn(torch.autograd.Function):
         y, _ = conv2d_raw(xd.view(1, 1, rows, Cin), w.view(Cp, 1, 1, Cin), b)
         ctx.save_for_backward(xd, w)
         ctx.Cout, ctx.has_bias = Cout, bias is not None
+        ctx.pkeys = (weight.data_ptr(),) + ((bias.data_ptr(),) if bias is not None else ())
         y = y.view(rows, Cp)
         return y if Cp == Cout else y[:, :Cout]
 
@@ -980,6 +998,7 @@ class LinearFn(torch.autograd.Function):
             wt = ctx.wt if ctx.wt is not None else weight_for_dgrad(w.view(Cp, 1, 1, Cin), flip=False)  # [Cin][1][1][Cp]
             dx, _ = conv2d_raw(dy.view(1, 1, rows, Cp), wt)
             dx = dx.view(rows, Cin)
+        _guard_shared_parameters(ctx.pkeys)
         return dx, dw, db
 
 

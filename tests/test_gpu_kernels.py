@@ -653,6 +653,76 @@ def test_od_loss_fused_matches_autograd(dtype, rtol, atol):
         _close(got, ref, 2e-5, 2e-5, f"losses (none_matched={none_matched})")
         for n, x, y in zip(("d_loc", "d_iou", "d_box", "d_cls"), b, a):
             _close(x.grad, y.grad, max(rtol, 1e-4), max(atol, 1e-5), f"{n} (none_matched={none_matched})")
+    # the REAL none_matched case: every ground truth degenerate, so the normalisers of the three unused terms are zero too
+    # (wsum = iou_norm = 0).  Their gradients must be exact zeros (not 0 * inf), the location term's gradient finite.
+    t.wts = torch.zeros_like(t.wts)
+    t.rel_iou = torch.zeros_like(t.rel_iou)
+    t.iou_norm, t.wsum = t.rel_iou.sum(), t.wts.sum()
+    t.none_matched = torch.tensor(True, device=DEV)
+    b = [h.clone().requires_grad_(True) for h in heads]
+    got = ops.od_loss(b[0], b[1], b[2], b[3], t)
+    got[0].backward()
+    assert torch.isfinite(got).all() and float(got[2]) == float(got[3]) == float(got[4]) == 0.0
+    assert torch.isfinite(b[0].grad).all() and float(b[0].grad.abs().max()) > 0
+    for x in b[1:]:
+        assert float(x.grad.float().abs().max()) == 0.0 and torch.isfinite(x.grad).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_od_laterals_written_into_the_flat_buffer(dtype):
+    """Inference: the detection head's laterals write their levels straight into the flat (B, P, C) position buffer
+    (conv out_image_stride; heads/object_detection.py:_flat_feats).  The buffer must be bit-equal to the concatenation of
+    the per-level outputs and to the CAT_LATERALS switch's path, in fp32 and bf16 (widths 32 and, in fp32, 36: a width that
+    is not a multiple of the 16-byte vector is refused by the normalised conv block itself, so the laterals have no other
+    fallback to cover)."""
+    import sihl_amd
+    from sihl_amd.heads import object_detection as od
+    torch.manual_seed(2)
+    for nc in ((32, 36) if dtype == torch.float32 else (32,)):
+        chans = [3, 8, 8, 16, 24, 40]
+        head = sihl_amd.heads.ObjectDetection(chans, num_classes=3, bottom_level=3, top_level=5, num_channels=nc).to(DEV).eval()
+        with torch.no_grad():
+            for lat in head.laterals:  # non-trivial running statistics
+                lat[1].running_mean.normal_()
+                lat[1].running_var.uniform_(0.5, 2.0)
+        feats = [torch.zeros(3, 3, 96, 64, device=DEV)] + [
+            torch.randn(3, c, 96 // 2 ** l, 64 // 2 ** l, device=DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+            for l, c in enumerate(chans[1:], start=1)]
+        with torch.no_grad():
+            try:
+                od.CAT_LATERALS = False
+                direct = head._flat_feats(feats)
+                od.CAT_LATERALS = True
+                cat = head._flat_feats(feats)
+            finally:
+                od.CAT_LATERALS = False
+            per_level = torch.cat([lat.forward_nhwc(_ops().nhwc(feats[l])).reshape(3, -1, nc) for lat, l in zip(head.laterals, head.levels)], 1)
+        assert direct.shape == cat.shape == (3, 12 * 8 + 6 * 4 + 3 * 2, nc)
+        assert torch.equal(direct, cat) and torch.equal(cat, per_level)
+        vec = 8 if dtype == torch.bfloat16 else 4
+        with torch.no_grad():
+            took_direct = head.laterals[0].forward_nhwc_into(_ops().nhwc(feats[3]), direct[:, :96], direct.shape[1] * nc)
+        assert bool(took_direct) == (nc % vec == 0)
+
+
+def test_od_training_step_with_only_degenerate_boxes():
+    """All ground-truth boxes degenerate (zero area): no anchor matches, the reference's early-out returns the location loss
+    alone (object_detection.py:165-172) - which is BCE / 0 there, i.e. not finite, as here.  What the sync-free restatement
+    must guarantee on top: the three unused terms are reported as zeros and their heads receive exact-zero gradients from the
+    fused loss kernel (not 0 * inf = NaN)."""
+    import sihl_amd
+    torch.manual_seed(1)
+    head = sihl_amd.heads.ObjectDetection([3, 8, 8, 32, 32, 32], num_classes=4, bottom_level=3, top_level=5, num_channels=32).to(DEV)
+    feats = [torch.zeros(2, 3, 64, 64, device=DEV)] + [torch.randn(2, c, 64 // 2 ** l, 64 // 2 ** l, device=DEV) for l, c in
+                                                       enumerate([8, 8, 32, 32, 32], start=1)]
+    boxes = [torch.tensor([[10.0, 10.0, 10.0, 30.0]], device=DEV), torch.tensor([[5.0, 7.0, 5.0, 7.0], [20.0, 20.0, 40.0, 20.0]], device=DEV)]
+    classes = [torch.tensor([1], device=DEV), torch.tensor([0, 3], device=DEV)]
+    loss, m = head.training_step(feats, classes, boxes)
+    loss.backward()
+    assert float(m["box_loss"]) == float(m["class_loss"]) == float(m["iou_loss"]) == 0.0
+    for sub in (head.box_head, head.cls_head, head.iou_head):
+        for p in sub.parameters():
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0
 
 
 # ------------------------------------------------------------------ BatchNorm + ReLU behind a foreign conv (the stem)
