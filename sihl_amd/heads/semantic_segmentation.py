@@ -104,15 +104,28 @@ class SemanticSegmentation(nn.Module):
         return ops.ce_resize(logits, targets.to(logits.device), self.ignore_index), {}
 
     def on_validation_start(self) -> None:
+        from sihl_amd.metrics import SegmentationConfusion
+
         self._val_losses: List[Tensor] = []
+        self._val_confusion = SegmentationConfusion(self.num_classes, self.ignore_index)
 
     def validation_step(self, inputs: List[Tensor], targets: Tensor) -> Tuple[Tensor, Dict[str, float]]:
-        loss, _ = self.training_step(inputs, targets)
+        """Loss + the reference's two metrics (:106-120): class maps at the targets' resolution from the fused nearest-resize
+        + softmax-max kernel (the argmax of the scores is the argmax of the logits), confusion counts kept on the device."""
+        import torch
+
+        with torch.no_grad():
+            logits = self._logits_nhwc(inputs)
+            targets = targets.to(logits.device)
+            loss = ops.ce_resize(logits, targets, self.ignore_index)
+            _, classes = ops.softmax_max_resize(logits, tuple(targets.shape[1:]))
+            self._val_confusion.update(classes, targets)
         self._val_losses.append(loss.detach())
         return loss, {}
 
     def on_validation_end(self) -> Dict[str, float]:
         import torch
 
-        # pixel accuracy / mean IoU need torchmetrics in the reference: out of scope here
-        return {"loss": torch.stack(self._val_losses).mean().item() if self._val_losses else float("nan")}
+        out = {"loss": torch.stack(self._val_losses).mean().item() if self._val_losses else float("nan")}
+        out.update(self._val_confusion.compute())
+        return out

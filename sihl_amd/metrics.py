@@ -130,3 +130,45 @@ class BoxMeanAveragePrecision:
             _, r = self._accumulate("all", m)
             out[f"mar_{m}"] = mean_valid(r)
         return out
+
+
+class SegmentationConfusion:
+    """Pixel accuracy and mean IoU of the reference's SemanticSegmentation validation (src/sihl/heads/
+    semantic_segmentation.py:94-120: torchmetrics ``Accuracy`` and ``JaccardIndex``, task "multiclass", default averaging),
+    restated from their published definitions on a confusion matrix that is accumulated ON THE DEVICE (one bincount per
+    validation step, no host synchronisation) and read once at the end:
+      * pixels whose target is ``ignore_index`` are dropped;
+      * pixel accuracy = micro average = correctly classified pixels / counted pixels;
+      * mean IoU = macro average of TP / (TP + FP + FN) over the classes that occur in the targets or the predictions
+        (a class absent from both has no IoU and does not enter the mean); when ``ignore_index`` is itself a class index it
+        is excluded from the mean as well.
+    "parity unpinned": torchmetrics is not importable here; tests check hand-computed cases."""
+
+    def __init__(self, num_classes: int, ignore_index=None) -> None:
+        self.num_classes, self.ignore_index = int(num_classes), ignore_index
+        self.confmat = None
+
+    def update(self, pred_classes: torch.Tensor, targets: torch.Tensor) -> None:
+        """pred_classes, targets: integer tensors of the same shape (any device); rows = target, columns = prediction."""
+        t = targets.reshape(-1).to(torch.int64)
+        p = pred_classes.reshape(-1).to(device=t.device, dtype=torch.int64)
+        keep = (t >= 0) & (t < self.num_classes)
+        if self.ignore_index is not None:
+            keep &= t != self.ignore_index
+        idx = torch.where(keep, t * self.num_classes + p.clamp(0, self.num_classes - 1), torch.full_like(t, self.num_classes ** 2))
+        counts = torch.bincount(idx, minlength=self.num_classes ** 2 + 1)[:-1]
+        self.confmat = counts if self.confmat is None else self.confmat + counts
+
+    def compute(self) -> Dict[str, float]:
+        if self.confmat is None:
+            return {"pixel_accuracy": float("nan"), "mean_iou": float("nan")}
+        cm = self.confmat.reshape(self.num_classes, self.num_classes).double().cpu()
+        tp = cm.diag()
+        total = cm.sum()
+        denom = cm.sum(0) + cm.sum(1) - tp
+        present = denom > 0
+        if self.ignore_index is not None and 0 <= self.ignore_index < self.num_classes:
+            present[self.ignore_index] = False
+        iou = tp[present] / denom[present]
+        return {"pixel_accuracy": float(tp.sum() / total) if total > 0 else float("nan"),
+                "mean_iou": float(iou.mean()) if present.any() else float("nan")}

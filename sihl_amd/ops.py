@@ -214,6 +214,18 @@ def weight_khwc(w: Tensor, dtype: torch.dtype) -> Tensor:
     prep = prepared(w, dtype)
     if prep is not None:
         return prep.w
+    if not torch.is_grad_enabled():
+        # inference outside a Trainer (model.eval()(x) in bf16 with no PreparedWeights): the operand copy is made once per
+        # weight version, not once per forward (~60 cast launches per BiFPN + head forward otherwise).  Same key as
+        # PreparedWeights: storage address + torch's version counter (writes through .data do not bump it).
+        key = (dtype, w.data_ptr(), w._version)
+        hit = getattr(w, "_sihl_cast", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        out = w.detach().permute(0, 2, 3, 1).to(dtype).contiguous()
+        if not torch.cuda.is_current_stream_capturing():
+            w._sihl_cast = (key, out)
+        return out
     return w.detach().permute(0, 2, 3, 1).to(dtype).contiguous()
 
 

@@ -113,6 +113,26 @@ def test_config2_resnet50_fpn_semseg_512_fp32_matches_oracle():
     h_model.zero_grad(set_to_none=True)
     # eval forward: (scores, classes) at input resolution; classes are integers and must agree wherever the two best
     # logits are not within rounding of each other
+    # validation metrics of the head (reference :94-120): accumulated on the device over two steps, against a direct
+    # computation from the head's own class maps
+    h_model.eval()
+    hh = h_model.heads[0]
+    hh.on_validation_start()
+    with torch.no_grad():
+        feats_a, feats_b = h_model.extract_features(x[:2].cuda()), h_model.extract_features(x[2:4].cuda())
+        hh.validation_step(feats_a, target[:2].cuda())
+        hh.validation_step(feats_b, target[2:4].cuda())
+        cls = torch.cat([hh.forward(feats_a)[1], hh.forward(feats_b)[1]]).cpu()
+    val = hh.on_validation_end()
+    tt = target[:4]
+    assert abs(val["pixel_accuracy"] - float((cls == tt).float().mean())) < 1e-9
+    ious = []
+    for c in range(NCLS):
+        inter, union = ((cls == c) & (tt == c)).sum().item(), ((cls == c) | (tt == c)).sum().item()
+        if union:
+            ious.append(inter / union)
+    assert abs(val["mean_iou"] - sum(ious) / len(ious)) < 1e-9 and val["loss"] == val["loss"]
+    h_model.train()
     h_model.load_state_dict(o_model.state_dict(), strict=True)  # identical running statistics for the eval pass
     o_model.eval(), h_model.eval()
     with torch.no_grad():

@@ -705,6 +705,29 @@ def test_od_laterals_written_into_the_flat_buffer(dtype):
         assert bool(took_direct) == (nc % vec == 0)
 
 
+def test_inference_operand_copies_are_cached_per_weight_version():
+    """model.eval()(x) in bf16 without a Trainer / PreparedWeights: the bf16 operand copy of a conv weight is made once per
+    weight VERSION (ops.weight_khwc), not per forward - and a weight changed in place is picked up."""
+    import sihl_amd
+    torch.manual_seed(0)
+    block = sihl_amd.layers.ConvNormAct(64, 64, 3).to(DEV).to(memory_format=torch.channels_last).eval()
+    x = torch.randn(2, 64, 32, 32, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = block[0].weight if hasattr(block, "__getitem__") else next(block.parameters())
+    with torch.no_grad():
+        y0 = block(x)
+        copy0 = w._sihl_cast[1]
+        y1 = block(x)
+        assert w._sihl_cast[1] is copy0 and torch.equal(y0, y1)  # no second cast
+        w.mul_(2.0)  # in place: bumps the version counter
+        y2 = block(x)
+        assert w._sihl_cast[1] is not copy0
+        torch.testing.assert_close(y2.float(), block(x).float())
+        assert float((y2.float() - y0.float()).abs().max()) > 1e-2
+    # under autograd the cache is not used (the cast is part of nothing autograd tracks, but training weights change every step)
+    y3 = block(x.requires_grad_(True))
+    assert y3.requires_grad
+
+
 def test_od_training_step_with_only_degenerate_boxes():
     """All ground-truth boxes degenerate (zero area): no anchor matches, the reference's early-out returns the location loss
     alone (object_detection.py:165-172) - which is BCE / 0 there, i.e. not finite, as here.  What the sync-free restatement

@@ -210,3 +210,27 @@ def test_box_map_matches_hand_computed_coco_protocol():
     m.update([{"scores": torch.tensor([0.5]), "labels": torch.tensor([0]), "boxes": torch.tensor([[0.0, 0, 100, 60]])}], gt)
     r = m.compute()  # IoU 0.6: true positive at 0.50, 0.55, 0.60 -> 3 of 10 thresholds
     assert abs(r["map"] - 0.3) < 1e-9 and r["map_50"] == 1.0 and r["map_75"] == 0.0
+
+
+def test_segmentation_confusion_metrics_hand_cases():
+    """Pixel accuracy (micro) and mean IoU (macro over the classes that occur) on cases worked out by hand."""
+    from sihl_amd.metrics import SegmentationConfusion
+
+    # 3 classes, 8 pixels.  target: 0 0 0 1 1 2 2 2 ; prediction: 0 0 1 1 1 2 0 2
+    t = torch.tensor([0, 0, 0, 1, 1, 2, 2, 2])
+    p = torch.tensor([0, 0, 1, 1, 1, 2, 0, 2])
+    m = SegmentationConfusion(3)
+    m.update(p[:5], t[:5])
+    m.update(p[5:], t[5:])  # accumulation over steps
+    r = m.compute()
+    assert abs(r["pixel_accuracy"] - 6 / 8) < 1e-12
+    # IoU: class 0: TP 2, FP 1 (pixel 6), FN 1 (pixel 2) -> 2/4; class 1: TP 2, FP 1, FN 0 -> 2/3; class 2: TP 2, FP 0, FN 1 -> 2/3
+    assert abs(r["mean_iou"] - (0.5 + 2 / 3 + 2 / 3) / 3) < 1e-12
+    # a class that never occurs (3 of 4) does not enter the mean; ignore_index drops pixels and its class
+    m = SegmentationConfusion(4, ignore_index=2)
+    m.update(p, t)
+    r = m.compute()
+    assert abs(r["pixel_accuracy"] - 4 / 5) < 1e-12  # pixels 0-4 counted: 4 correct
+    # class 0: TP 2, FP 0 (pixel 6 was ignored), FN 1 -> 2/3; class 1: TP 2, FP 1, FN 0 -> 2/3; classes 2 (ignored), 3 (absent) out
+    assert abs(r["mean_iou"] - 2 / 3) < 1e-12
+    assert SegmentationConfusion(3).compute()["mean_iou"] != SegmentationConfusion(3).compute()["mean_iou"]  # NaN before any update
