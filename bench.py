@@ -283,6 +283,8 @@ def main():
     ap.add_argument("--memory-map", default="",
                     help="diagnostic only: write allocator segments + named tensors (tools/graph_fault_map.py) to this "
                          "file right before the timed steps")
+    ap.add_argument("--krot", type=int, default=-1,
+                    help="A/B: sihl_conv2d_krot value (stage stride between workgroups' K-loop starts; + 1000 x minimum stages)")
     ap.add_argument("--main-priority", type=int, default=0,
                     help="A/B: run the step on a user stream of this HIP priority (-1 = high) instead of the default stream")
     ap.add_argument("--no-fused-loss", action="store_true",
@@ -379,6 +381,8 @@ def main():
         with torch.cuda.stream(extra):
             _dummy = torch.zeros(1024, device=device).add_(1)
         torch.cuda.synchronize()
+    if args.krot >= 0:
+        _C.lib().sihl_conv2d_krot(args.krot)
     if args.main_priority:
         torch.cuda.synchronize()
         _main = torch.cuda.Stream(device=device, priority=args.main_priority)

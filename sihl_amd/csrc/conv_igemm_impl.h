@@ -913,8 +913,11 @@ int launch_dma(const ConvParams& p0, hipStream_t stream) {
                          p.stats_mode == 0 && !p.bias && !p.pre_scale && !p.post_scale;
   const void* late_add = (p.add && !fused_add && p.splits == 1) ? p.add : nullptr;  // split-K adds in its finisher
   if (late_add) p.add = nullptr;
-  p.k_rotate = (!(g_rules_off & 4) && p.splits == 1 && p.gridM * p.gridN >= 64 &&
-                ((p.Cin + KCB / (int)sizeof(T) - 1) / (KCB / (int)sizeof(T))) * p.KH * p.KW >= 8) ? g_krot : 0;
+  {
+    const int min_stages = g_krot / 1000 ? g_krot / 1000 : 8;  // (tuning: sihl_conv2d_krot(1000 * min_stages + stride))
+    p.k_rotate = (!(g_rules_off & 4) && p.splits == 1 && p.gridM * p.gridN >= 64 &&
+                  ((p.Cin + KCB / (int)sizeof(T) - 1) / (KCB / (int)sizeof(T))) * p.KH * p.KW >= min_stages) ? g_krot % 1000 : 0;
+  }
   auto kern = p.in_dilate > 1 ? conv_igemm_dma_kernel<T, BM, BN, WM, WN, true, NBUF>
                               : conv_igemm_dma_kernel<T, BM, BN, WM, WN, false, NBUF>;
   if constexpr (CAN_ADD) {

@@ -319,7 +319,7 @@ int sihl_small_launch(const ConvParams& p0, hipStream_t stream) {
   p.splits = small_splits(p);
   p.small_nch = p.Cin / 64 / p.splits;
   p.dbg = g_dbg;  // read by the kernel in SIHL_TUNING builds only
-  p.k_rotate = g_krot != 0;
+  p.k_rotate = g_krot % 1000 != 0;
   const double flops = 2.0 * p.M * (double)p.Cout * 9 * p.Cin;
   const double bytes = ((double)p.N * p.H * p.W * p.Cin + (double)p.M * p.Cout + (double)p.Cout * 9 * p.Cin) * 2.0;
   sihl_prof_begin(SIHL_PROF_CONV, SIHL_BF16, flops, bytes, stream);

@@ -48,6 +48,18 @@ def _stream():
 
 
 _WS = {}
+_SIZES = {}
+
+
+def _sized(name: str, *args):
+    """Result of one of the library's pure size helpers (`*_ws_bytes`, `*_stat_rows`: functions of the shape alone),
+    memoised: a training step asked the same ~150 questions through ctypes every step (~0.7 ms of host time)."""
+    key = (name,) + args
+    v = _SIZES.get(key)
+    if v is None:
+        v = _SIZES[key] = getattr(_C.lib(), name)(*args)
+    return v
+
 _SPLIT_TAIL_BWD = bool(os.environ.get("SIHL_SPLIT_TAIL_BWD"))
 
 # ---- BatchNorm step counters: one multi-tensor add per training step instead of one tiny kernel per layer
@@ -214,7 +226,7 @@ def weight_khwc(w: Tensor, dtype: torch.dtype) -> Tensor:
     prep = prepared(w, dtype)
     if prep is not None:
         return prep.w
-    if not torch.is_grad_enabled():
+    if not torch.is_grad_enabled() and w.is_cuda:
         # inference outside a Trainer (model.eval()(x) in bf16 with no PreparedWeights): the operand copy is made once per
         # weight version, not once per forward (~60 cast launches per BiFPN + head forward otherwise).  Same key as
         # PreparedWeights: storage address + torch's version counter (writes through .data do not bump it).
@@ -336,11 +348,11 @@ def conv2d_raw(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, stride: int 
         out = torch.empty((N, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
     stats, stats_bytes = None, 0
     if stats_mode:
-        rows = _C.lib().sihl_conv2d_stat_rows(N * Ho * Wo)
+        rows = _sized("sihl_conv2d_stat_rows", N * Ho * Wo)
         stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
         stats_bytes = stats.numel() * 4
     lib = _C.lib()
-    ws_bytes = lib.sihl_conv2d_ws_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad, dil)  # > 0: tiny level, split-K
+    ws_bytes = _sized("sihl_conv2d_ws_bytes", N, H, W, Cin, Cout, KH, KW, stride, pad, dil)  # > 0: tiny level, split-K
     ws = workspace(ws_bytes, x.device) if ws_bytes else None
     rc = lib.sihl_conv2d_fwd_ws(
         _p(x), _p(w), _p(bias), _p(out), N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x), ACT[act],
@@ -361,7 +373,7 @@ def conv2d_wgrad_raw(x: Tensor, dout: Tensor, KH: int, KW: int, stride: int, pad
     dw = torch.empty((Cout, KH, KW, Cin), dtype=torch.float32, device=x.device)
     side = _SIDE
     if side is not None and dout.numel() // Cout <= WGRAD_SIDE_MAX_PIXELS[side.mode]:
-        nbytes = lib.sihl_conv2d_wgrad_ws_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x), SIDE_WGRAD_TARGET)
+        nbytes = _sized("sihl_conv2d_wgrad_ws_bytes", N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x), SIDE_WGRAD_TARGET)
         side.stream.wait_stream(torch.cuda.current_stream())  # x and dout are complete on the main stream
         with torch.cuda.stream(side.stream):
             ws = workspace(nbytes, x.device)  # the side stream's own scratch buffer (keyed by stream)
@@ -370,7 +382,7 @@ def conv2d_wgrad_raw(x: Tensor, dout: Tensor, KH: int, KW: int, stride: int, pad
         side.holds.append((x, dout, dw))
         side.dirty = True
     else:
-        nbytes = lib.sihl_conv2d_wgrad_ws_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x), WGRAD_TARGET)
+        nbytes = _sized("sihl_conv2d_wgrad_ws_bytes", N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x), WGRAD_TARGET)
         ws = workspace(nbytes, x.device)
         rc = lib.sihl_conv2d_wgrad(_p(x), _p(dout), _p(dw), N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x), 0,
                                    WGRAD_TARGET, _p(ws), ws.numel(), _stream())
@@ -462,7 +474,7 @@ def norm_act_bwd(s: Tensor, dy: Tensor, mean, rstd, gamma, beta, mode: int, act,
     C = s.shape[-1]
     rows = s.numel() // C
     lib = _C.lib()
-    ws = workspace(lib.sihl_norm_act_bwd_ws_bytes(rows, C, _dt(s)), s.device)
+    ws = workspace(_sized("sihl_norm_act_bwd_ws_bytes", rows, C, _dt(s)), s.device)
     dz = torch.empty_like(s)
     dgamma = torch.empty(C, dtype=torch.float32, device=s.device)
     dbeta = torch.empty_like(dgamma)
@@ -478,7 +490,7 @@ def norm_add_relu_bwd(s: Tensor, dy: Tensor, y: Tensor, mean, rstd, gamma, beta,
     C = s.shape[-1]
     rows = s.numel() // C
     lib = _C.lib()
-    ws = workspace(lib.sihl_norm_act_bwd_ws_bytes(rows, C, _dt(s)), s.device)
+    ws = workspace(_sized("sihl_norm_act_bwd_ws_bytes", rows, C, _dt(s)), s.device)
     dres, dz = torch.empty_like(s), torch.empty_like(s)
     dgamma = torch.empty(C, dtype=torch.float32, device=s.device)
     dbeta = torch.empty_like(dgamma)
@@ -500,12 +512,12 @@ def colsum(x: Tensor, off_chain: bool = False) -> Tensor:
     if side is not None and rows <= WGRAD_SIDE_MAX_PIXELS[side.mode]:
         side.stream.wait_stream(torch.cuda.current_stream())  # x is complete on the main stream
         with torch.cuda.stream(side.stream):
-            ws = workspace(lib.sihl_colsum_ws_bytes(rows, C), x.device)
+            ws = workspace(_sized("sihl_colsum_ws_bytes", rows, C), x.device)
             rc = lib.sihl_colsum(_p(x), rows, C, _p(out), _dt(x), _p(ws), ws.numel(), _stream())
         side.holds.append((x, x, out))
         side.dirty = True
     else:
-        ws = workspace(lib.sihl_colsum_ws_bytes(rows, C), x.device)
+        ws = workspace(_sized("sihl_colsum_ws_bytes", rows, C), x.device)
         rc = lib.sihl_colsum(_p(x), rows, C, _p(out), _dt(x), _p(ws), ws.numel(), _stream())
     check(rc, "sihl_colsum")
     return out
@@ -657,7 +669,7 @@ class ConvBlockFn(torch.autograd.Function):
             Cin = x.shape[-1]
             dxs = torch.empty((N, Ho, Wo, Cin), dtype=x.dtype, device=x.device)
             lib = _C.lib()
-            ws_bytes = lib.sihl_conv2d_ws_bytes(N, Ho, Wo, Cout, Cin, 1, 1, 1, 0, 1)
+            ws_bytes = _sized("sihl_conv2d_ws_bytes", N, Ho, Wo, Cout, Cin, 1, 1, 1, 0, 1)
             ws = workspace(ws_bytes, x.device) if ws_bytes else None
             rc = lib.sihl_conv2d_dgrad_ws(_p(dz), _p(wt), _p(dxs), None, N, Ho, Wo, Cin, Cout, 1, 1, 1, 0, 1, _dt(x),
                                           _p(ws), ws.numel() if ws is not None else 0, _stream())
@@ -668,7 +680,7 @@ class ConvBlockFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             N, H, W, Cin = x.shape
             lib = _C.lib()
-            ws_bytes = lib.sihl_conv2d_ws_bytes(N, H, W, w.shape[0], Cin, KH, KW, 1, dil * (KH - 1) - pad, dil) \
+            ws_bytes = _sized("sihl_conv2d_ws_bytes", N, H, W, w.shape[0], Cin, KH, KW, 1, dil * (KH - 1) - pad, dil) \
                 if stride == 1 else 0
             ws = workspace(ws_bytes, x.device) if ws_bytes else None
             add, add_stride = None, 1
@@ -1038,7 +1050,7 @@ class LayerNormActFn(torch.autograd.Function):
         dy = dy.contiguous()
         rows, C = z.shape
         lib = _C.lib()
-        ws = workspace(lib.sihl_layernorm_act_bwd_ws_bytes(rows, C), z.device)
+        ws = workspace(_sized("sihl_layernorm_act_bwd_ws_bytes", rows, C), z.device)
         dz = torch.empty_like(z)
         dgamma = torch.empty(C, dtype=torch.float32, device=z.device)
         dbeta = torch.empty_like(dgamma)
