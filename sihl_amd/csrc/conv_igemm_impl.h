@@ -1064,7 +1064,13 @@ int dispatch(const ConvParams& p, hipStream_t stream) {
       if (g_tile_override == 2562) return launch_dma<T, 128, 256, 2, 4, 2>(p, stream);
       if (g_tile_override == 2563) return launch_dma<T, 128, 256, 2, 4, 3>(p, stream);
       // windowed convs over 16 k - 64 k pixels into 256 channels (P4 3x3 at batch 32: 256 workgroups, one per CU, the
-      // whole weight panel width per workgroup): 46 us against 52 for 512 single-stage 128x128 tiles (tools/tile_probe.py)
+      // whole weight panel width per workgroup): 46 us against 52 for 512 single-stage 128x128 tiles (tools/tile_probe.py).
+      // (A halo-resident variant of this level - 256 pixels x 128 channels per workgroup, the input patch fetched once
+      // instead of once per tap, 0.76 MB of LDS-DMA ingest per CU instead of 1.73 - was built in round 3 and measured
+      // SLOWER: 2.300 ms per north-star forward with 8 waves of 64 x 64, 2.391 with 4 waves of 64 x 128, against 2.270 for
+      // this tile, profiles/r03_halo_p4_ab.txt.  The level is not ingest-bound: its matrix loop alone takes 37 of the 47 us,
+      // because 64 x 64 wave tiles need one ds_read_b128 per MFMA and two such waves per SIMD sit exactly at the LDS array's
+      // 256 B/clk, while the tiles that halve the LDS traffic leave half the chip or half the SIMD slots empty at this size.)
       if (g_tile_override == 0 && !(g_rules_off & 8) && p.KH * p.KW > 1 && p.Cout == 256 && tiles128 >= 128 && tiles128 <= 384)
         return launch_dma<T, 128, 256, 2, 4, 2>(p, stream);
     }

@@ -34,8 +34,8 @@ VARIANTS = [("default (small-level conv, register MLP, rotated K loops, P4 on 12
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 res = {v[0]: [] for v in VARIANTS}
 for rnd in range(rounds):
-    for name, small, mlp, krot, mrot in VARIANTS:
-        variant(small, mlp, krot, mrot)
+    for name, small, mlp, krot, roff in VARIANTS:
+        variant(small, mlp, krot, roff)
         r = bench.north_star_forward(model, dev, torch.bfloat16, 32, 512, iters=40)
         res[name].append(r["ms"])
 variant(1, "rows", 13, 0)
