@@ -505,17 +505,19 @@ def main():
     # HBM traffic of the conv kernel per launch: PMC counters need their own rocprofv3 passes (FETCH_SIZE, WRITE_SIZE;
     # profiles/pmc_summarize.py applies the gfx950 correction), so the figure comes from the committed summary of
     # those passes over this same command, not from this run
-    traffic, traffic_note = None, "no PMC summary for this source tree (profiles/r02_pmc_bench.json)"
+    pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_bench.json") and f[:1] == "r")
+    pmc_name = pmc_files[-1] if pmc_files else "r03_pmc_bench.json"  # the newest round's summary
+    traffic, traffic_note = None, f"no PMC summary for this source tree (profiles/{pmc_name})"
     try:
-        pmc_all = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_bench.json")))
+        pmc_all = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
         pmc = pmc_all["kernels"]["conv_igemm_dma_kernel"]
         if pmc_all.get("source_stamp") != source_stamp():
-            traffic_note = (f"profiles/r02_pmc_bench.json was measured on other kernel sources (stamp "
+            traffic_note = (f"profiles/{pmc_name} was measured on other kernel sources (stamp "
                             f"{pmc_all.get('source_stamp')} != {source_stamp()}): stale, not reported")
         elif args.dtype == "bf16" and args.batch == 32 and args.size == 512:
             traffic = pmc["traffic_MB_per_launch"] * 1e6
             traffic_note = ("HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes over this "
-                            "command, profiles/r02_pmc_bench.json, same source stamp); algorithmic bytes per launch: "
+                            f"command, profiles/{pmc_name}, same source stamp); algorithmic bytes per launch: "
                             "avg_algorithmic_mb_per_launch")
     except (OSError, KeyError, ValueError):
         pass

@@ -32,7 +32,8 @@ def family(n):
     for key in ("conv_igemm_dma_kernel", "conv_igemm_kernel", "conv_wgrad_dma_kernel", "conv_wgrad_alltaps_kernel",
                 "conv_wgrad_kernel", "wgrad_reduce_kernel", "norm_bwd_apply_kernel", "norm_bwd_reduce_kernel",
                 "affine_act_bwd_kernel", "affine_act_kernel", "layernorm_act_bwd_kernel", "layernorm_act_kernel",
-                "weight_prepare_t_kernel", "weight_prepare_kernel", "conv_splitk_epilogue_kernel"):
+                "weight_prepare_t_kernel", "weight_prepare_kernel", "conv_splitk_epilogue_kernel", "conv_small_kernel",
+                "mlp_rows_kernel", "blur_fuse_kernel", "fuse_up2_kernel"):
         if key in n:
             return key
     return None
