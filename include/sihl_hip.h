@@ -91,7 +91,7 @@ int sihl_conv2d_dgrad_add(const void* dout, const void* wt_t, void* din, const v
 int sihl_conv2d_splitk_enable(int on); /* tuning / test hook */
 int sihl_conv2d_small_enable(int on);  /* tuning / test hook: 0 = 3x3 convs of the small pyramid levels on the general kernel, not csrc/conv_small.hip */
 int sihl_conv2d_rules_off(int mask);   /* tuning hook: disable individual dispatch rules */
-int sihl_conv2d_krot(int n);           /* tuning hook: stage stride between neighbouring workgroups' K-loop starts (default 13, 0 = lockstep) */
+int sihl_conv2d_krot(int n);           /* tuning hook: stage stride between neighbouring workgroups' K-loop starts (100000 * log2(group) + 1000 * min_stages + stride; default 200013 = groups of 4 workgroups share a start, stride 13; 0 = lockstep) */
 
 /* Weight gradient (autograd of Conv2d.weight / Linear.weight): dw fp32 [Cout][KH][KW][Cin];
  * accumulate != 0 adds into dw.  Cin, Cout % vector == 0. */

@@ -5,7 +5,7 @@
 #include "conv_params.h"
 #include "conv_tuning.h"
 
-ConvTuning sihl_conv_tuning = {false, 0, 0, 0, true, true, 0, 13};
+ConvTuning sihl_conv_tuning = {false, 0, 0, 0, true, true, 0, 200013};
 
 extern "C" {
 
@@ -54,7 +54,9 @@ int sihl_conv2d_rules_off(int mask) { g_rules_off = mask; return 0; }
 // Tuning / test hook: 0 = the small pyramid levels' 3x3 convs take the general kernel instead of conv_small.hip.
 int sihl_conv2d_small_enable(int on) { sihl_small_set_enabled(on != 0); return 0; }
 
-// Tuning hook: stage stride between neighbouring workgroups' K-loop starts (0 = lockstep).
+// Tuning hook: 100000 * log2(group) + 1000 * min_stages + stride - the stage stride between the K-loop starts of
+// neighbouring GROUPS of workgroups (default 200013: groups of 4 share a start and with it their L2 fills, stride 13;
+// 0 = lockstep).
 int sihl_conv2d_krot(int n) { g_krot = n < 0 ? 0 : n; return 0; }
 
 // Tuning / test hook: 0 disables split-K.
@@ -109,7 +111,7 @@ int sihl_conv2d_fwd_ws(const void* in, const void* wt, const float* bias, void* 
   p.splits = 1; p.partial = (float*)ws; p.partial_bytes = ws ? ws_bytes : 0;
   p.add = nullptr; p.add_stride = 1; p.add_H = p.add_W = 0;
   p.w_ntaps = KH * KW; p.w_kw = KW; p.w_ky0 = p.w_kx0 = 0; p.w_kys = p.w_kxs = 1;
-  p.k_rotate = 0; p.small_nch = 0;
+  p.k_rotate = 0; p.k_rot_group = 0; p.small_nch = 0;
   p.out_s = 1; p.out_py = p.out_px = 0; p.out_W = p.Wo;
   if (dtype == SIHL_F32) return sihl_conv_dispatch_f32(p, stream);
   if (dtype == SIHL_BF16) return sihl_conv_dispatch_bf16(p, stream);
@@ -169,7 +171,7 @@ int sihl_conv2d_dgrad_add(const void* dout, const void* wt_t, void* din, const v
   p.add_stride = add ? add_stride : 1;
   p.add_H = (H + add_stride - 1) / add_stride; p.add_W = (W + add_stride - 1) / add_stride;
   p.w_ntaps = KH * KW; p.w_kw = KW; p.w_ky0 = p.w_kx0 = 0; p.w_kys = p.w_kxs = 1;
-  p.k_rotate = 0; p.small_nch = 0;
+  p.k_rotate = 0; p.k_rot_group = 0; p.small_nch = 0;
   p.out_s = 1; p.out_py = p.out_px = 0; p.out_W = W;
   // 3x3 / stride 2 / pad 1 (the strided convs of the ResNet stages): four parity classes of output pixels, each a small
   // dense conv over dout with the 1, 2, 2 or 4 weight taps that meet it (dx[2i+py] = sum_ky dout[(2i+py+1-ky)/2] w[ky]

@@ -481,7 +481,7 @@ __global__ __launch_bounds__(WM * WN * 64, (conv_min_waves<BM, BN>())) void conv
   // reads the SAME weight panel, and workgroups started together walk it in lockstep: each 32 KiB weight stage is then
   // requested by all of an XCD's workgroups at once.  Rotated starts spread the panel's lines over the L2 channels at any
   // moment (the fp32 sum of a tile is taken in another stage order: deterministic, tile by tile).
-  const int s_first = p.k_rotate ? (int)(((unsigned)L * (unsigned)p.k_rotate) % (unsigned)total_stages) : (int)blockIdx.y * per_split;
+  const int s_first = p.k_rotate ? (int)((((unsigned)L >> p.k_rot_group) * (unsigned)p.k_rotate) % (unsigned)total_stages) : (int)blockIdx.y * per_split;
   const int nstages = p.k_rotate ? total_stages : min(total_stages, s_first + per_split) - s_first;
 
   const v4i_t in_rsrc = make_rsrc(p.in, (unsigned)((long)p.N * p.H * p.W * p.Cin * (long)sizeof(T)));
@@ -914,7 +914,8 @@ int launch_dma(const ConvParams& p0, hipStream_t stream) {
   const void* late_add = (p.add && !fused_add && p.splits == 1) ? p.add : nullptr;  // split-K adds in its finisher
   if (late_add) p.add = nullptr;
   {
-    const int min_stages = g_krot / 1000 ? g_krot / 1000 : 8;  // (tuning: sihl_conv2d_krot(1000 * min_stages + stride))
+    const int min_stages = (g_krot / 1000) % 100 ? (g_krot / 1000) % 100 : 8;  // (tuning: sihl_conv2d_krot(100000 * log2(group) + 1000 * min_stages + stride))
+    p.k_rot_group = g_krot / 100000;  // 2^k neighbouring workgroups share a start (and their L2 fills)
     p.k_rotate = (!(g_rules_off & 4) && p.splits == 1 && p.gridM * p.gridN >= 64 &&
                   ((p.Cin + KCB / (int)sizeof(T) - 1) / (KCB / (int)sizeof(T))) * p.KH * p.KW >= min_stages) ? g_krot % 1000 : 0;
   }

@@ -37,6 +37,7 @@ struct ConvParams {
   // kx*w_kxs) - and scatters output pixel (i, j) to (i*out_s + out_py, j*out_s + out_px) of an out_W-wide image.
   int w_ntaps, w_kw, w_ky0, w_kys, w_kx0, w_kxs;  // defaults: KH*KW, KW, 0, 1, 0, 1
   int out_s, out_py, out_px, out_W;                // defaults: 1, 0, 0, Wo
+  int k_rot_group;  // log2 of the number of neighbouring workgroups that share a K-loop start
   int k_rotate;     // LDS-DMA tile kernel: workgroups start their K loop at different stages (see conv_igemm_dma_kernel)
   int small_nch;    // conv_small.hip (3x3 on the small pyramid levels): channel chunks one workgroup walks
   int add_stride;   // > 1: the addend is [N][add_H][add_W][Cout] and lands on output pixels (y, x) with y % add_stride

@@ -11,7 +11,7 @@ struct ConvTuning {
   bool splitk;           // tuning / test hook: split-K for tiny pyramid levels
   bool strided_classes;  // tuning / test hook: parity-class dgrad of 3x3 stride-2 convs (else zero-dilated read)
   int rules_off;         // tuning hook: bit 0 = no single-stage narrow tiles, bit 1 = no 128x128 routing of thin pointwise layers, bit 2 = K loops in lockstep
-  int krot;              // tuning hook: stage stride between neighbouring workgroups' K-loop starts (default 13)
+  int krot;              // tuning hook: stage stride between neighbouring workgroups' K-loop starts (default 200013 = groups of 4 workgroups, stride 13; see sihl_conv2d_krot)
 };
 extern ConvTuning sihl_conv_tuning;
 #define g_force_reg (sihl_conv_tuning.force_reg)
