@@ -280,9 +280,6 @@ def main():
     ap.add_argument("--graph-warmup-stream", default="off", choices=["off", "small", "all"],
                     help="debugging only, with --graph: stream mode of the eager warm-up steps before the capture (the "
                          "round-1 fault needed 'all'; a graph Trainer otherwise never uses a second stream)")
-    ap.add_argument("--memory-map", default="",
-                    help="diagnostic only: write allocator segments + named tensors (tools/graph_fault_map.py) to this "
-                         "file right before the timed steps")
     ap.add_argument("--krot", type=int, default=-1,
                     help="A/B: sihl_conv2d_krot value (stage stride between workgroups' K-loop starts; + 1000 x minimum stages)")
     ap.add_argument("--main-priority", type=int, default=0,
@@ -394,10 +391,6 @@ def main():
         trace(f"warm-up step {i} issued")
     sync()
     trace("warm-up done")
-    if args.memory_map:
-        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
-        from graph_fault_map import take_snapshot
-        take_snapshot(model, trainer, {}, "before the timed steps", args.memory_map)
     allocs0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):

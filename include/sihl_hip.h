@@ -226,7 +226,6 @@ int sihl_mlp_fwd(const void* x, long x_stride, long rows, int Cin, int C, int nh
  * for l >= 1 must be in the K order sihl_mlp_permute_k produces (inside each group of 16 input channels
  * [0-3, 8-11, 4-7, 12-15] - the order in which a lane's accumulators hold a row's channels); w[0] is plain. */
 int sihl_mlp_rows_supported(long rows, int Cin, int C, int Cout, int nhidden, int act, int dtype);
-int sihl_mlp_rows_delay(int n); /* tuning hook: start delay of alternate workgroups, x 4096 cycles */
 /* Up to 4 such MLPs in ONE launch (the class / box heads of a detection head: the same few thousand rows, each MLP alone
  * fills a tenth of the chip for the same 35 us); same activation for all, they may share x. */
 typedef struct sihl_mlp_call {

@@ -31,7 +31,6 @@ SIGNATURES = {
     "sihl_mlp_fwd_supported": (I, [L, I, I, I, I, I, I]),
     "sihl_mlp_fwd": (I, [P, L, L, I, I, I, P, P, P, P, F, I, I, P, I, I, P]),
     "sihl_mlp_rows_supported": (I, [L, I, I, I, I, I, I]),
-    "sihl_mlp_rows_delay": (I, [I]),
     "sihl_mlp_rows_fwd_multi": (I, [P, I, I, I, P]),
     "sihl_mlp_rows_debug": (I, [I]),
     "sihl_mlp_permute_k": (I, [P, P, L, I, P]),

@@ -97,7 +97,7 @@ __device__ __forceinline__ void mlp_rows_stage(f32x16_t (&acc)[8], const uint4 (
 // Hidden layers are full width (C == 256: 8 blocks, compile-time - a run-time block count puts the accumulators behind
 // branches and hipcc then spills them).
 template <int SILU, int LASTB>
-__global__ __launch_bounds__(RTHREADS, 2) void mlp_rows_kernel(const MlpRowsBatch pb, const float floor_, const int delay) {
+__global__ __launch_bounds__(RTHREADS, 2) void mlp_rows_kernel(const MlpRowsBatch pb, const float floor_) {
   // several MLPs in one launch (the class and box heads of a detection head run over the same few thousand rows: each
   // alone fills a tenth of the chip for the same 35 us)
   int which = 0;
@@ -159,11 +159,8 @@ __global__ __launch_bounds__(RTHREADS, 2) void mlp_rows_kernel(const MlpRowsBatc
   };
   issue_stage();
   __syncthreads();  // the parameter vectors are in LDS
-  // Two workgroups share a CU so that one normalises (VALU) while the other multiplies (MFMA) - which they only do when
-  // they are out of phase; identical workgroups started together stay in lockstep.  Every other pair of XCD rounds starts
-  // `delay` x 64 x 64 cycles late.
-  if (delay > 0 && ((blockIdx.x >> 3) & 1))
-    for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(64);
+  // (Tried: a start delay for alternate workgroups, to put the two workgroups of a CU out of phase - one normalising while
+  // the other multiplies.  Monotonically slower, 143.5 -> 160.9 us for 0 -> 6 x 4096 cycles: not kept.)
 
   const float inv_c = 1.f / 256.f;
   int slot = 0;
@@ -304,7 +301,6 @@ __global__ void mlp_permute_k_kernel(const uint2* __restrict__ in, uint2* __rest
   }
 }
 
-int g_mlp_rows_delay = 0;
 int g_mlp_rows_dbg = 0;
 template <int SILU, int LASTB>
 int launch_mlp_rows(const MlpRowsBatch& pb, int n, float floor_, hipStream_t stream) {
@@ -318,7 +314,7 @@ int launch_mlp_rows(const MlpRowsBatch& pb, int n, float floor_, hipStream_t str
     if (e != hipSuccess) return (int)e;
     attr_lds = lds;
   }
-  hipLaunchKernelGGL((mlp_rows_kernel<SILU, LASTB>), dim3(pb.first_block[n]), dim3(RTHREADS), lds, stream, pb, floor_, g_mlp_rows_delay);
+  hipLaunchKernelGGL((mlp_rows_kernel<SILU, LASTB>), dim3(pb.first_block[n]), dim3(RTHREADS), lds, stream, pb, floor_);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
 }
@@ -334,9 +330,6 @@ int sihl_mlp_rows_supported(long rows, int Cin, int C, int Cout, int nhidden, in
          Cout <= 256 && nhidden >= 1 && nhidden <= MLPR_MAXL && C == 256 &&
          (act == SIHL_ACT_SILU || act == SIHL_ACT_RELU || act == SIHL_ACT_NONE);
 }
-
-// Tuning hook: start delay of alternate workgroups, in units of 4096 cycles (0 = none).
-int sihl_mlp_rows_delay(int n) { g_mlp_rows_delay = n < 0 ? 0 : n; return SIHL_OK; }
 
 // Tuning ablation (`make TUNING=1` builds only; results invalid when non-zero): see MlpRowsParams::dbg.
 int sihl_mlp_rows_debug(int mode) { g_mlp_rows_dbg = mode; return SIHL_OK; }

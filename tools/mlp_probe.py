@@ -72,12 +72,7 @@ for rows, cout in ((174592, 1), (3200, 80)):
         def direct_rows():
             lib.sihl_mlp_rows_fwd(x.data_ptr(), 256, rows, 256, 256, 4, plan_r.w_rows, plan_r.bias, plan_r.gamma, plan_r.beta,
                                   1e-5, 2, cout, out.data_ptr(), cp, 1, torch.cuda.current_stream().cuda_stream)
-        line = "   direct launches, registers kernel, start delay x4096 cycles:"
-        for d in (0,):
-            lib.sihl_mlp_rows_delay(d)
-            line += f" {d}: {timed(direct_rows, 50):6.1f} |"
-        lib.sihl_mlp_rows_delay(0)
-        print(line, flush=True)
+        print(f"   direct launches, registers kernel: {timed(direct_rows, 50):6.1f} us", flush=True)
         if os.environ.get("SIHL_HIP_LIB"):
             line = "   registers kernel ablations:"
             for name, mode in (("all", 0), ("no LN", 1), ("no DMA", 2), ("no MFMA", 4), ("no LN no DMA", 3), ("no LN no MFMA", 5),
