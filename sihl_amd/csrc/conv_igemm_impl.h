@@ -14,8 +14,9 @@
 // K is walked in stages of (one tap) x (128 bytes of input channels = 64 bf16 / 32 fp32): the A tile
 // (BM pixel rows, zero-filled outside the image) and the B tile (BN weight rows) are staged
 // global -> registers -> LDS (rows padded to 144 B: conflict-free ds_read_b128 for the 32x32 MFMA
-// operand shape), double-buffered, one barrier per stage.  bf16 uses v_mfma_f32_32x32x16_bf16 with
-// fp32 accumulation; fp32 uses v_mfma_f32_32x32x2_f32 (exact fp32, for the 1e-4 parity configuration).
+// operand shape), double-buffered, one barrier per stage.  bf16 uses v_mfma_f32_16x16x32_bf16 in the LDS-DMA kernels
+// (v_mfma_f32_32x32x16_bf16 in the register-staged fallback) with fp32 accumulation; fp32 uses v_mfma_f32_32x32x2_f32
+// (exact fp32, for the 1e-4 parity configuration).
 // Epilogue: bias -> [stats] -> pre-affine -> activation -> [stats] -> post-affine, the tile is
 // transposed through LDS and written with 16-byte row-contiguous stores; per-channel (sum, sumsq)
 // partials for BatchNorm batch statistics go to a workspace row per M-tile (deterministic, no atomics).
@@ -43,41 +44,45 @@ __device__ __forceinline__ long add_offset(const ConvParams& p, int m) {
 constexpr int KCB = 128;         // bytes of K per stage per row
 constexpr int LDS_STRIDE = 144;  // padded row (bytes)
 
-template <typename T> __device__ __forceinline__ void mma_step(f32x16_t& c, const uint4& a, const uint4& b);
-template <> __device__ __forceinline__ void mma_step<bf16_t>(f32x16_t& c, const uint4& a, const uint4& b) {
-#ifdef SIHL_MFMA16_TIMING
-  // TIMING EXPERIMENT ONLY (results are garbage): the same flops issued as two 16x16x32 instructions per 32x32x16, to
-  // see what the other MFMA shape's clock behaviour (MI355X_MICROARCH.md, DVFS item 7) would be worth in this loop
-  f32x4_t c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
-  c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c0, 0, 0, 0);
-  c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c1, 0, 0, 0);
-  c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3]; c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
-#else
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-#endif
-}
-template <> __device__ __forceinline__ void mma_step<float>(f32x16_t& c, const uint4& a, const uint4& b) {
-  // lane half h holds k = 4h..4h+3 of this 8-wide k-step: MFMA j contracts k = {j, 4+j}
-  c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
-}
+// MFMA output-tile geometry.  The bf16 LDS-DMA kernels multiply with v_mfma_f32_16x16x32_bf16 (TILE 16: 4 accumulator
+// registers per tile, lane -> column lane % 16, rows 4 * (lane / 16) + r); fp32 (exact v_mfma_f32_32x32x2_f32) and the
+// register-staged fallback use 32 x 32 tiles (16 registers: column lane % 32, rows 8 * (r / 4) + 4 * (lane / 32) + r % 4).
+// In both, register r of lane group g = lane / TILE is row (r & 3) + (256 / TILE) * (r >> 2) + 4 * g of the tile, and
+// registers r, r + 1 (r even) are neighbouring rows.  Why 16x16x32: the same flops per ds_read_b128 and per cycle, but the
+// chip holds a higher clock under it (MI355X_MICROARCH.md, bare-loop 1.12-1.15 x); measured on this loop: L3 3x3
+// 154 -> 144 us, MLP linears 56 -> 48 (profiles/r02_mfma_shape_timing.txt was the timing-only preview).
+template <int TILE> struct AccTile { typedef float type __attribute__((ext_vector_type(TILE * TILE / 64))); };
+template <int TILE> __device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + (256 / TILE) * (r >> 2); }
 
+template <typename T, int TILE> __device__ __forceinline__ void mma_step(typename AccTile<TILE>::type& c, const uint4& a, const uint4& b) {
+  if constexpr (sizeof(T) == 2 && TILE == 16) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  } else if constexpr (sizeof(T) == 2) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  } else {
+    static_assert(TILE == 32, "fp32: 32x32x2 MFMA");
+    // lane half h holds k = 4h..4h+3 of this 8-wide k-step: MFMA j contracts k = {j, 4+j}
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+}
 // Shared epilogue: bias -> [stats] -> pre-affine -> act -> [stats] -> post-affine, LDS transpose, row stores.
 // ACT and STATS are compile-time inside the element loop (a runtime switch there costs an expf per element).
-template <typename T, int BM, int BN, int WM, int WN, int ACT, int STATS, bool ADD = false>
-__device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32],
+template <typename T, int BM, int BN, int WM, int WN, int ACT, int STATS, bool ADD = false, int TILE = 32>
+__device__ __forceinline__ void conv_epilogue_body(const ConvParams& p,
+                                                   typename AccTile<TILE>::type (&acc)[BM / WM / TILE][BN / WN / TILE],
                                                    char* smem, int tile_m, int m0, int n0) {
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int NTHREADS = WM * WN * 64;
-  constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NT = WTN / 32;
+  constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / TILE, NT = WTN / TILE, REGS = TILE * TILE / 64;
   constexpr int EPI_STRIDE = BN * (int)sizeof(T) + 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   char* epi = smem;
   float* red = (float*)(smem + BM * EPI_STRIDE);  // [2][WM][BN]
-  const int half = lane >> 5;
+  const int grp = lane / TILE;  // lane group: rows 4 * grp + ... of every tile
   const bool has_pre = p.pre_scale != nullptr, has_post = p.post_scale != nullptr;
   // The element loop is VALU-bound on store-heavy layers (64 elements per lane at ~10 instructions each: a thin
   // pointwise conv spent more time here than loading, multiplying and storing).  The common training launch - no
@@ -96,7 +101,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t
       constexpr bool POST = decltype(post_tag)::value;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const int cl = wn * WTN + j * 32 + (lane & 31);
+        const int cl = wn * WTN + j * TILE + (lane & (TILE - 1));
         const bool cok = n0 + cl < p.Cout;
         const float bias = (p.bias && cok) ? p.bias[n0 + cl] : 0.f;
         const float s2 = (POST && cok) ? p.post_scale[n0 + cl] : 1.f;
@@ -107,12 +112,12 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t
           typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
           f32x2_t sum2 = {0.f, 0.f}, sq2 = {0.f, 0.f};
           const f32x2_t b2 = {bias, bias}, s2v = {s2, s2}, t2v = {t2, t2};
-          char* col = epi + (wm * WTM + 4 * half) * EPI_STRIDE + cl * 2;
+          char* col = epi + (wm * WTM + 4 * grp) * EPI_STRIDE + cl * 2;
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-              const int row = i * 32 + (r & 3) + 8 * (r >> 2);  // (+ wm*WTM + 4*half in `col`); register r + 1 is row + 1
+            for (int r = 0; r < REGS; r += 2) {
+              const int row = i * TILE + acc_row<TILE>(r);  // (+ wm*WTM + 4*grp in `col`); register r + 1 is row + 1
               f32x2_t v = {acc[i][j][r], acc[i][j][r + 1]};
               v += b2;  // (a bias-free instantiation would save half an instruction per output and double the epilogue code)
               if (STATS == 1) { sum2 += v; sq2 = __builtin_elementwise_fma(v, v, sq2); }
@@ -132,8 +137,8 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          for (int r = 0; r < REGS; ++r) {
+            const int row = wm * WTM + i * TILE + acc_row<TILE>(r) + 4 * grp;
             float v = acc[i][j][r] + bias;
             if (STATS == 1) { ssum += v; ssq += v * v; }
             if (ACT == SIHL_ACT_RELU) v = fmaxf(v, 0.f);
@@ -146,9 +151,12 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t
         }
         }
         if (STATS) {
-          ssum += __shfl_xor(ssum, 32);
-          ssq += __shfl_xor(ssq, 32);
-          if (half == 0) {
+#pragma unroll
+          for (int o = TILE; o < 64; o <<= 1) {  // fold the lane groups (same column, other rows)
+            ssum += __shfl_xor(ssum, o);
+            ssq += __shfl_xor(ssq, o);
+          }
+          if (grp == 0) {
             red[(0 * WM + wm) * BN + cl] = ssum;
             red[(1 * WM + wm) * BN + cl] = ssq;
           }
@@ -160,7 +168,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t
   } else
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int cl = wn * WTN + j * 32 + (lane & 31);  // column inside the tile
+    const int cl = wn * WTN + j * TILE + (lane & (TILE - 1));  // column inside the tile
     const int co = n0 + cl;
     const bool cok = co < p.Cout;
     const float bias = (p.bias && cok) ? p.bias[co] : 0.f;
@@ -172,8 +180,8 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      for (int r = 0; r < REGS; ++r) {
+        const int row = wm * WTM + i * TILE + acc_row<TILE>(r) + 4 * grp;
         float v = acc[i][j][r] + bias;
         if (STATS == 1) { const float m = (m0 + row) < p.M ? v : 0.f; ssum += m; ssq += m * m; }
         v = v * s1 + t1;
@@ -186,9 +194,12 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t
       }
     }
     if (STATS) {
-      ssum += __shfl_xor(ssum, 32);
-      ssq += __shfl_xor(ssq, 32);
-      if (half == 0) {
+#pragma unroll
+      for (int o = TILE; o < 64; o <<= 1) {
+        ssum += __shfl_xor(ssum, o);
+        ssq += __shfl_xor(ssq, o);
+      }
+      if (grp == 0) {
         red[(0 * WM + wm) * BN + cl] = ssum;
         red[(1 * WM + wm) * BN + cl] = ssq;
       }
@@ -287,22 +298,23 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvParams& p, f32x16_t
   }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
-__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], char* smem,
+template <typename T, int BM, int BN, int WM, int WN, int TILE = 32>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p,
+                                              typename AccTile<TILE>::type (&acc)[BM / WM / TILE][BN / WN / TILE], char* smem,
                                               int tile_m, int m0, int n0) {
   // the combinations the hot path uses get their own straight-line body; the rest share the generic ones
   if (p.stats_mode == 0) {
-    if (p.act == SIHL_ACT_NONE) conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_NONE, 0>(p, acc, smem, tile_m, m0, n0);
-    else if (p.act == SIHL_ACT_RELU) conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_RELU, 0>(p, acc, smem, tile_m, m0, n0);
-    else if (p.act == SIHL_ACT_SILU) conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_SILU, 0>(p, acc, smem, tile_m, m0, n0);
-    else conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_SIGMOID, 0>(p, acc, smem, tile_m, m0, n0);
+    if (p.act == SIHL_ACT_NONE) conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_NONE, 0, false, TILE>(p, acc, smem, tile_m, m0, n0);
+    else if (p.act == SIHL_ACT_RELU) conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_RELU, 0, false, TILE>(p, acc, smem, tile_m, m0, n0);
+    else if (p.act == SIHL_ACT_SILU) conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_SILU, 0, false, TILE>(p, acc, smem, tile_m, m0, n0);
+    else conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_SIGMOID, 0, false, TILE>(p, acc, smem, tile_m, m0, n0);
   } else if (p.stats_mode == 1) {
-    conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_NONE, 1>(p, acc, smem, tile_m, m0, n0);  // conv -> BN -> act
+    conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_NONE, 1, false, TILE>(p, acc, smem, tile_m, m0, n0);  // conv -> BN -> act
   } else {
-    if (p.act == SIHL_ACT_RELU) conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_RELU, 2>(p, acc, smem, tile_m, m0, n0);
-    else if (p.act == SIHL_ACT_NONE) conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_NONE, 2>(p, acc, smem, tile_m, m0, n0);
-    else if (p.act == SIHL_ACT_SILU) conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_SILU, 2>(p, acc, smem, tile_m, m0, n0);
-    else conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_SIGMOID, 2>(p, acc, smem, tile_m, m0, n0);
+    if (p.act == SIHL_ACT_RELU) conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_RELU, 2, false, TILE>(p, acc, smem, tile_m, m0, n0);
+    else if (p.act == SIHL_ACT_NONE) conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_NONE, 2, false, TILE>(p, acc, smem, tile_m, m0, n0);
+    else if (p.act == SIHL_ACT_SILU) conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_SILU, 2, false, TILE>(p, acc, smem, tile_m, m0, n0);
+    else conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_SIGMOID, 2, false, TILE>(p, acc, smem, tile_m, m0, n0);
   }
 }
 
@@ -411,7 +423,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) mma_step<T>(acc[i][j], a[i], b[j]);
+        for (int j = 0; j < NT; ++j) mma_step<T, 32>(acc[i][j], a[i], b[j]);
     }
   };
 
@@ -456,10 +468,11 @@ __global__ __launch_bounds__(WM * WN * 64, (conv_min_waves<BM, BN>())) void conv
   constexpr int NTHREADS = WM * WN * 64;
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int KCE = KCB / (int)sizeof(T);
-  constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NT = WTN / 32;
+  constexpr int TILE = sizeof(T) == 2 ? 16 : 32;  // MFMA tile (see AccTile)
+  constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / TILE, NT = WTN / TILE, REGS = TILE * TILE / 64;
   constexpr int A_BYTES = BM * KCB, B_BYTES = BN * KCB, STAGE = A_BYTES + B_BYTES;
   constexpr int NA = BM * 8 / NTHREADS, NBL = BN * 8 / NTHREADS;  // 16-byte slots per thread per stage
-  constexpr int NKS = KCB / 32;                                    // k-steps per stage
+  constexpr int NKS = KCB / (TILE == 16 ? 64 : 32);                // k-steps per stage (one ds_read_b128 per lane and k-step)
   constexpr int PER_STAGE = NA + NBL;                              // DMA instructions per thread per stage
   static_assert(NA >= 1 && NBL >= 1, "tile too small for the thread count");
   static_assert(NBUF >= 1 && NBUF <= 4 && (NBUF < 2 || (NBUF - 2) * PER_STAGE <= 63), "vmcnt immediate range");
@@ -580,18 +593,21 @@ __global__ __launch_bounds__(WM * WN * 64, (conv_min_waves<BM, BN>())) void conv
     dma16(voff, n_bbase + j * 1024, wt_rsrc);
   };
 
-  f32x16_t acc[MT][NT];
+  typename AccTile<TILE>::type acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < REGS; ++r) acc[i][j][r] = 0.f;
 
-  const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
+  // fragment reads: lane -> row fr of a TILE-row block, 16-byte chunk ks * (64 / TILE) + fg of the stage's 128 bytes of K
+  // (16x16x32: the four 16-lane groups take four consecutive chunks = K 0..31 of the step).  With the source-side XOR both
+  // shapes put the 16 lanes of every ds_read_b128 group on 16 distinct 4-bank slots.
+  const int fr = lane & (TILE - 1), fg = lane / TILE, fsw = (fr >> 1) & 7;
   int koff[NKS];
 #pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) koff[ks] = fr * KCB + (((ks * 2 + fh) ^ fsw) << 4);
+  for (int ks = 0; ks < NKS; ++ks) koff[ks] = fr * KCB + (((ks * (64 / TILE) + fg) ^ fsw) << 4);
 
   // wait until at most `keep` of the newest stage groups are still in flight (vm ops retire in order)
   auto wait_keep = [&](int keep) {
@@ -619,13 +635,13 @@ __global__ __launch_bounds__(WM * WN * 64, (conv_min_waves<BM, BN>())) void conv
       for (int ks = 0; ks < ((SIHL_DBG(p) & 2) ? 0 : NKS); ++ks) {
         uint4 fa[MT], fb[NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) fa[i] = *(const uint4*)(As + i * 32 * KCB + koff[ks]);
+        for (int i = 0; i < MT; ++i) fa[i] = *(const uint4*)(As + i * TILE * KCB + koff[ks]);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) fb[j] = *(const uint4*)(Bs + j * 32 * KCB + koff[ks]);
+        for (int j = 0; j < NT; ++j) fb[j] = *(const uint4*)(Bs + j * TILE * KCB + koff[ks]);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) mma_step<T>(acc[i][j], fa[i], fb[j]);
+          for (int j = 0; j < NT; ++j) mma_step<T, TILE>(acc[i][j], fa[i], fb[j]);
       }
       __syncthreads();  // everyone is done with the stage before it is overwritten (or reused by the epilogue)
     }
@@ -655,12 +671,13 @@ __global__ __launch_bounds__(WM * WN * 64, (conv_min_waves<BM, BN>())) void conv
     //   3: front-loaded - slots spread over the first half of the k-steps
     const int sched = (SIHL_DBG(p) & 16) ? ((SIHL_DBG(p) >> 2) & 3) : ((BM >= 256 && NBUF == 2) ? 3 : 1);
     const bool early = sched == 1 || (sched == 2 && wave < WM * WN / 2);
+    constexpr int NKSH = NKS / 2 > 0 ? NKS / 2 : 1;
     if (!(SIHL_DBG(p) & 2)) {
       uint4 fa[2][MT], fb[2][NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) fa[0][i] = *(const uint4*)(As + i * 32 * KCB + koff[0]);
+      for (int i = 0; i < MT; ++i) fa[0][i] = *(const uint4*)(As + i * TILE * KCB + koff[0]);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) fb[0][j] = *(const uint4*)(Bs + j * 32 * KCB + koff[0]);
+      for (int j = 0; j < NT; ++j) fb[0][j] = *(const uint4*)(Bs + j * TILE * KCB + koff[0]);
       if (more && early) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) issue_a(j);
@@ -671,14 +688,14 @@ __global__ __launch_bounds__(WM * WN * 64, (conv_min_waves<BM, BN>())) void conv
       for (int ks = 0; ks < NKS; ++ks) {
         if (ks + 1 < NKS) {  // fragments of the next k-step are in flight while this one multiplies
 #pragma unroll
-          for (int i = 0; i < MT; ++i) fa[(ks + 1) & 1][i] = *(const uint4*)(As + i * 32 * KCB + koff[ks + 1]);
+          for (int i = 0; i < MT; ++i) fa[(ks + 1) & 1][i] = *(const uint4*)(As + i * TILE * KCB + koff[ks + 1]);
 #pragma unroll
-          for (int j = 0; j < NT; ++j) fb[(ks + 1) & 1][j] = *(const uint4*)(Bs + j * 32 * KCB + koff[ks + 1]);
+          for (int j = 0; j < NT; ++j) fb[(ks + 1) & 1][j] = *(const uint4*)(Bs + j * TILE * KCB + koff[ks + 1]);
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) mma_step<T>(acc[i][j], fa[ks & 1][i], fb[ks & 1][j]);
+          for (int j = 0; j < NT; ++j) mma_step<T, TILE>(acc[i][j], fa[ks & 1][i], fb[ks & 1][j]);
         if (more && !early) {
           if (sched == 0) {
 #pragma unroll
@@ -692,11 +709,13 @@ __global__ __launch_bounds__(WM * WN * 64, (conv_min_waves<BM, BN>())) void conv
 #pragma unroll
               for (int j = 0; j < NBL; ++j) issue_b(j);
             }
-          } else if (ks < NKS / 2) {
+          } else if (ks < NKSH) {
+            // (one block per k-step, not a slice after every row of MFMA tiles: interleaved that finely the L3 3x3 took
+            // 157 us instead of 143 - the two waves of a SIMD alternate best with one in its DMA block, one multiplying)
 #pragma unroll
-            for (int j = ks; j < NA; j += NKS / 2) issue_a(j);
+            for (int j = ks; j < NA; j += NKSH) issue_a(j);
 #pragma unroll
-            for (int j = ks; j < NBL; j += NKS / 2) issue_b(j);
+            for (int j = ks; j < NBL; j += NKSH) issue_b(j);
           }
         }
       }
@@ -706,6 +725,12 @@ __global__ __launch_bounds__(WM * WN * 64, (conv_min_waves<BM, BN>())) void conv
 #pragma unroll
       for (int j = 0; j < NBL; ++j) issue_b(j);
     }
+    // (the multiplies stay above the wait: with two 32-deep k-steps per stage the scheduler otherwise sinks the second
+    // k-step's MFMAs - register operands only - below the barrier, and the next stage's DMA flight is covered by nothing.
+    // Also tried on the 256 x 256 tile, round 3: the barrier taken 1-2 MFMA rows before the end of the stage with the next
+    // stage's first fragments read behind it, DMA block after 0 / 2 / 4 rows, half the waves issuing early - all within
+    // 1 % of this form on L3 3x3, lat3 1x1 and r2 1x1 128>512, gpurun_out mf16/variants2.txt; not kept.)
+    __builtin_amdgcn_sched_barrier(0);
     // stage s+1 must have landed: only the stages issued after it may still be in flight ...
     wait_keep(max(0, min(NBUF - 2, nstages - 2 - s)));
     __syncthreads();  // ... for every wave, and everyone is done reading stage s
@@ -716,22 +741,21 @@ __global__ __launch_bounds__(WM * WN * 64, (conv_min_waves<BM, BN>())) void conv
   if (SIHL_DBG(p) & 32) return;  // tuning ablation: no epilogue
   if (p.splits > 1) {  // raw fp32 partial tile; conv_splitk_epilogue_kernel sums the splits and finishes
     float* part = p.partial + (long)blockIdx.y * p.M * p.Cout;
-    const int half = lane >> 5;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int co = n0 + wn * WTN + j * 32 + (lane & 31);
+      const int co = n0 + wn * WTN + j * TILE + (lane & (TILE - 1));
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        for (int r = 0; r < REGS; ++r) {
+          const int m = m0 + wm * WTM + i * TILE + acc_row<TILE>(r) + 4 * fg;
           if (m < p.M && co < p.Cout) part[(long)m * p.Cout + co] = acc[i][j][r];
         }
     }
     return;
   }
-  if constexpr (ADD) conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_NONE, 0, true>(p, acc, smem, tile_m, m0, n0);
-  else conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, tile_m, m0, n0);
+  if constexpr (ADD) conv_epilogue_body<T, BM, BN, WM, WN, SIHL_ACT_NONE, 0, true, TILE>(p, acc, smem, tile_m, m0, n0);
+  else conv_epilogue<T, BM, BN, WM, WN, TILE>(p, acc, smem, tile_m, m0, n0);
 }
 
 // out += add over n elements (fallback for tile configurations without an ADD instantiation)
