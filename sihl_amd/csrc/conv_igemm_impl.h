@@ -459,12 +459,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 // waves per SIMD the tile is tuned for (its workgroups share a CU to hide each other's load -> multiply -> store phases):
 // passed to __launch_bounds__ so that an epilogue change cannot silently cost a resident workgroup (the packed bf16
 // epilogue did: 128x128 went from 160 to 171 registers, 3 -> 2 workgroups per CU)
-template <int BM, int BN> constexpr int conv_min_waves() {
-  return (BM == 128 && BN == 64) ? 5 : (BM == 128 && BN == 128) ? 3 : (BM == 256) ? 2 : 1;
+template <int BM, int BN, int NW = 8> constexpr int conv_min_waves() {
+  return (BM == 128 && BN == 64) ? 5 : (BM == 128 && BN == 128) ? 3 : (BM == 256) ? (NW == 16 ? 4 : 2) : 1;
 }
 
 template <typename T, int BM, int BN, int WM, int WN, bool DIL, int NBUF, bool ADD = false>
-__global__ __launch_bounds__(WM * WN * 64, (conv_min_waves<BM, BN>())) void conv_igemm_dma_kernel(const ConvParams p) {
+__global__ __launch_bounds__(WM * WN * 64, (conv_min_waves<BM, BN, WM * WN>())) void conv_igemm_dma_kernel(const ConvParams p) {
   constexpr int NTHREADS = WM * WN * 64;
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int KCE = KCB / (int)sizeof(T);
@@ -1083,7 +1083,11 @@ int dispatch(const ConvParams& p, hipStream_t stream) {
       // window lose (r2 128>512: 63 -> 66, L3 3x3: 156 -> 182)
       if (g_tile_override == 0 && !(g_rules_off & 2) && p.M >= 256 * 256 && p.KH * p.KW == 1 && p.Cin <= 256 && p.Cout <= 256)
         return launch_n128<T>(p, stream);
-      if (g_tile_override == 256 || (g_tile_override == 0 && p.M >= 256 * 256)) return launch_dma<T, 256, 256, 4, 2>(p, stream);
+      // 16 waves of 64 x 64 (4 per SIMD, 118 registers) rather than 8 of 64 x 128: half the LDS-DMA instructions per wave
+      // and stage, and four waves per SIMD to cover each other's DMA-issue and barrier phases - L3 3x3 146 -> 143 us,
+      // lat3 1x1 56.4 -> 53.7, r2 1x1 128>512 56.2 -> 51.4 (tools/tile_probe.py, profiles/r03_tile_probe_mfma16.txt)
+      if (g_tile_override == 2568) return launch_dma<T, 256, 256, 4, 2>(p, stream);  // (A/B: the 8-wave form)
+      if (g_tile_override == 256 || (g_tile_override == 0 && p.M >= 256 * 256)) return launch_dma<T, 256, 256, 4, 4>(p, stream);
     }
     if constexpr (sizeof(T) == 2) {  // 128 pixels x 256 channels on 8 waves (2 x 4), 2 / 3 LDS stages
       if (g_tile_override == 2562) return launch_dma<T, 128, 256, 2, 4, 2>(p, stream);

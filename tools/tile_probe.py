@@ -11,7 +11,8 @@ from sihl_amd import _C, ops  # noqa: E402
 dev, dt = "cuda", torch.bfloat16
 lib = _C.lib()
 SHAPES = [("L3 3x3", 32, 64, 64, 256, 256, 3), ("L4 3x3", 32, 32, 32, 256, 256, 3), ("L5 3x3", 32, 16, 16, 256, 256, 3),
-          ("L6 3x3", 32, 8, 8, 256, 256, 3), ("L7 3x3", 32, 4, 4, 256, 256, 3), ("mlp 1x1", 1, 1, 174592, 256, 256, 1)]
+          ("L6 3x3", 32, 8, 8, 256, 256, 3), ("L7 3x3", 32, 4, 4, 256, 256, 3), ("mlp 1x1", 1, 1, 174592, 256, 256, 1),
+          ("lat3 1x1", 32, 64, 64, 512, 256, 1), ("r2 128>512", 32, 64, 64, 128, 512, 1), ("r1 64>256", 32, 128, 128, 64, 256, 1)]
 NB = 8
 
 
@@ -41,7 +42,8 @@ for name, N, H, W, Cin, Cout, K in SHAPES:
     sc, sh = torch.rand(Cout, device=dev) + 0.5, torch.randn(Cout, device=dev)
     flops = 2.0 * N * H * W * Cin * Cout * K * K
     line = f"{name:10s} {flops / 1e9:7.1f} GF"
-    for tname, tile, nb in (("auto", 0, 0), ("256x256", 256, 0), ("128x256w8/2", 2562, 0), ("128x256w8/3", 2563, 0),
+    for tname, tile, nb in (("auto", 0, 0), ("256x256w16", 256, 0), ("256x256w8", 2568, 0), ("256x256w16", 256, 0),
+                            ("256x256w8", 2568, 0), ("128x256w8/2", 2562, 0), ("128x256w8/3", 2563, 0),
                             ("128x128/1", 1280, 1), ("128x128/2", 1280, 2), ("128x64/2", 64, 2), ("128x64/4", 64, 4)):
         lib.sihl_conv2d_tile_override(tile)
         lib.sihl_conv2d_nbuf_override(nb)
