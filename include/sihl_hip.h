@@ -174,11 +174,14 @@ int sihl_fuse_up2(const void* a, const void* b, const float* wraw, void* out, in
                   hipStream_t stream);
 int sihl_fuse_up2_bwd(const void* dout, const void* a, const void* b, const float* wraw, void* da, void* db,
                       float* dw_raw, float* gacc, int N, int H, int W, int C, int dtype, hipStream_t stream);
-int sihl_blur_fuse(const void* a, const void* b, const void* c, const float* wraw, void* out, int N, int H, int W,
-                   int C, int dtype, hipStream_t stream);
-int sihl_blur_fuse_bwd(const void* dout, const void* a, const void* b, const void* c, const float* wraw, void* da,
-                       void* db, void* dc, float* dw_raw, float* gacc, int N, int H, int W, int C, int dtype,
-                       hipStream_t stream);
+/* a_scale / a_shift (fp32 [C], both or neither): `a` stands for a * scale + shift - the training-mode BatchNorm affine of
+ * the ConvNormAct that produced it (layers/scalers.py:26-30 AntialiasedDownscaler = conv block -> BlurPool2d), applied to
+ * the blurred value instead of in a pass of its own; the backward's `da` is then the gradient of a * scale + shift. */
+int sihl_blur_fuse(const void* a, const void* b, const void* c, const float* wraw, const float* a_scale,
+                   const float* a_shift, void* out, int N, int H, int W, int C, int dtype, hipStream_t stream);
+int sihl_blur_fuse_bwd(const void* dout, const void* a, const void* b, const void* c, const float* wraw,
+                       const float* a_scale, const float* a_shift, void* da, void* db, void* dc, float* dw_raw,
+                       float* gacc, int N, int H, int W, int C, int dtype, hipStream_t stream);
 int sihl_fuse_sum(const void* x0, const void* x1, const void* x2, const float* wraw, void* out, long numel, int n,
                   int dtype, hipStream_t stream);
 int sihl_fuse_sum_bwd(const void* dout, const void* x0, const void* x1, const void* x2, const float* wraw, void* d0,

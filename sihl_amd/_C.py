@@ -73,8 +73,8 @@ SIGNATURES = {
     "sihl_maxpool3x3s2_bwd": (I, [P, P, P, I, I, I, I, I, P]),
     "sihl_fuse_sum": (I, [P, P, P, P, P, L, I, I, P]),
     "sihl_fuse_sum_bwd": (I, [P, P, P, P, P, P, P, P, P, P, L, I, I, P]),
-    "sihl_blur_fuse": (I, [P, P, P, P, P, I, I, I, I, I, P]),
-    "sihl_blur_fuse_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "sihl_blur_fuse": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "sihl_blur_fuse_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "sihl_layernorm_act": (I, [P, P, L, I, P, P, F, I, P, P, I, P]),
     "sihl_layernorm_bwd_waves": (I, [L]),
     "sihl_layernorm_act_bwd_ws_bytes": (L, [L, I]),

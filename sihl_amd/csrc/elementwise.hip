@@ -513,10 +513,14 @@ __global__ void resize_bilinear_adjoint_kernel(const T* __restrict__ dout, T* __
 
 // ------------------------------------------------------------------ blur (reflect, [1,2,1]^2/16, stride 2) + fuse
 // out = w0*blur(a) + w1*b + w2*c       a: [N][H][W][C]; b,c,out: [N][Ho][Wo][C]; b==null -> out = blur(a)
+// a_scale / a_shift (optional, per channel): `a` stands for a * scale + shift - the BatchNorm affine of the conv block
+// that produced it (training: conv -> ReLU -> BN), applied to the blurred value (the taps sum to 1) instead of in a
+// pass of its own over the full-resolution tensor.
 // One output row per blockIdx.y (image and the three reflected source rows: scalar), 32-bit arithmetic - see fuse_up2_kernel.
 template <typename T>
 __global__ void blur_fuse_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c,
-                                 const float* __restrict__ wraw, T* __restrict__ out, int N, int H, int W, int Ho,
+                                 const float* __restrict__ wraw, const float* __restrict__ a_scale,
+                                 const float* __restrict__ a_shift, T* __restrict__ out, int N, int H, int W, int Ho,
                                  int Wo, int C) {
   constexpr int V = 16 / sizeof(T);
   const unsigned cvec = C / V;
@@ -548,6 +552,13 @@ __global__ void blur_fuse_kernel(const T* __restrict__ a, const T* __restrict__ 
       for (int e = 0; e < V; ++e) acc[e] += k * f[e];
     }
   }
+  if (a_scale) {
+    float sc[V], sf[V];
+    ldparam<V>(a_scale, cv * V, sc, 1.f);
+    ldparam<V>(a_shift, cv * V, sf, 0.f);
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = acc[e] * sc[e] + sf[e];
+  }
   const long i = ((long)row * Wo + ox) * C + cv * V;
   if (b) {
     float fb[V], fc[V];
@@ -562,8 +573,10 @@ __global__ void blur_fuse_kernel(const T* __restrict__ a, const T* __restrict__ 
 // low-res pass of the adjoint: db = w1*dout, dc = w2*dout, g += <dout, {blur(a), b, c}>
 template <typename T>
 __global__ void blur_fuse_bwd_lo_kernel(const T* __restrict__ dout, const T* __restrict__ a, const T* __restrict__ b,
-                                        const T* __restrict__ c, const float* __restrict__ wraw, T* __restrict__ db,
-                                        T* __restrict__ dc, float* gacc, int N, int H, int W, int Ho, int Wo, int C) {
+                                        const T* __restrict__ c, const float* __restrict__ wraw,
+                                        const float* __restrict__ a_scale, const float* __restrict__ a_shift,
+                                        T* __restrict__ db, T* __restrict__ dc, float* gacc, int N, int H, int W, int Ho,
+                                        int Wo, int C) {
   constexpr int V = 16 / sizeof(T);
   const int cvec = C / V;
   const long nvec = (long)N * Ho * Wo * cvec;
@@ -598,6 +611,13 @@ __global__ void blur_fuse_bwd_lo_kernel(const T* __restrict__ dout, const T* __r
 #pragma unroll
           for (int e = 0; e < V; ++e) bl[e] += k * f[e];
         }
+      }
+      if (a_scale) {
+        float sc[V], sf[V];
+        ldparam<V>(a_scale, cv * V, sc, 1.f);
+        ldparam<V>(a_shift, cv * V, sf, 0.f);
+#pragma unroll
+        for (int e = 0; e < V; ++e) bl[e] = bl[e] * sc[e] + sf[e];
       }
 #pragma unroll
       for (int e = 0; e < V; ++e) { g[0] += d[e] * bl[e]; g[1] += d[e] * fb[e]; g[2] += d[e] * fc[e]; }
@@ -1553,9 +1573,10 @@ int sihl_fuse_sum_bwd(const void* dout, const void* x0, const void* x1, const vo
 }
 
 // out[N][Ho][Wo][C] = w0*blurpool_s2(a[N][H][W][C]) + w1*b + w2*c ; b==c==null -> plain blur pool
-int sihl_blur_fuse(const void* a, const void* b, const void* c, const float* wraw, void* out, int N, int H, int W,
-                   int C, int dtype, hipStream_t stream) {
+int sihl_blur_fuse(const void* a, const void* b, const void* c, const float* wraw, const float* a_scale,
+                   const float* a_shift, void* out, int N, int H, int W, int C, int dtype, hipStream_t stream) {
   if (!a || !out || N <= 0 || H < 2 || W < 2 || ((b != nullptr) != (c != nullptr)) || (b && !wraw)) return SIHL_EARG;
+  if ((a_scale != nullptr) != (a_shift != nullptr)) return SIHL_EARG;
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   DISPATCH_DTYPE(dtype, {
     constexpr int V = 16 / sizeof(T);
@@ -1563,17 +1584,20 @@ int sihl_blur_fuse(const void* a, const void* b, const void* c, const float* wra
     const long rows = (long)N * Ho;  // grid.(y, z) = output rows
     if (rows > 65535L * 65535L || (long)W * C >= (1L << 31)) return SIHL_EARG;
     hipLaunchKernelGGL(blur_fuse_kernel<T>, dim3((Wo * (C / V) + TPB - 1) / TPB, (unsigned)(rows < 65535 ? rows : 65535), (unsigned)((rows + 65534) / 65535)), dim3(TPB), 0, stream,
-                       (const T*)a, (const T*)b, (const T*)c, wraw, (T*)out, N, H, W, Ho, Wo, C);
+                       (const T*)a, (const T*)b, (const T*)c, wraw, a_scale, a_shift, (T*)out, N, H, W, Ho, Wo, C);
   });
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
 }
 
 // fused (b != null): gacc 3 floats; plain blur (b == null): only da is produced
-int sihl_blur_fuse_bwd(const void* dout, const void* a, const void* b, const void* c, const float* wraw, void* da,
-                       void* db, void* dc, float* dw_raw, float* gacc, int N, int H, int W, int C, int dtype,
-                       hipStream_t stream) {
+// a_scale / a_shift: as in sihl_blur_fuse; `da` is then the gradient of a * scale + shift (what the producing conv
+// block's BatchNorm backward takes), the fusion-weight gradient uses the blurred affine value
+int sihl_blur_fuse_bwd(const void* dout, const void* a, const void* b, const void* c, const float* wraw,
+                       const float* a_scale, const float* a_shift, void* da, void* db, void* dc, float* dw_raw,
+                       float* gacc, int N, int H, int W, int C, int dtype, hipStream_t stream) {
   if (!dout || N <= 0 || H < 2 || W < 2 || (dw_raw && (!gacc || !b))) return SIHL_EARG;
+  if ((a_scale != nullptr) != (a_shift != nullptr)) return SIHL_EARG;
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   if (dw_raw) { hipError_t e = hipMemsetAsync(gacc, 0, 3 * sizeof(float), stream); if (e) return (int)e; }
   DISPATCH_DTYPE(dtype, {
@@ -1581,8 +1605,8 @@ int sihl_blur_fuse_bwd(const void* dout, const void* a, const void* b, const voi
     if (C % V) return SIHL_EARG;
     if (b && (db || dc || dw_raw))
       hipLaunchKernelGGL(blur_fuse_bwd_lo_kernel<T>, dim3(grid_for((long)N * Ho * Wo * (C / V))), dim3(TPB), 0,
-                         stream, (const T*)dout, (const T*)a, (const T*)b, (const T*)c, wraw, (T*)db, (T*)dc,
-                         dw_raw ? gacc : nullptr, N, H, W, Ho, Wo, C);
+                         stream, (const T*)dout, (const T*)a, (const T*)b, (const T*)c, wraw, a_scale, a_shift, (T*)db,
+                         (T*)dc, dw_raw ? gacc : nullptr, N, H, W, Ho, Wo, C);
     if (da)
       hipLaunchKernelGGL(blur_adjoint_kernel<T>, dim3(grid_for((long)N * H * W * (C / V))), dim3(TPB), 0, stream,
                          (const T*)dout, b ? wraw : nullptr, (T*)da, N, H, W, Ho, Wo, C);

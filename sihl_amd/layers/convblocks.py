@@ -40,7 +40,9 @@ class _ConvBlock(nn.Sequential):
         norm = next((m for m in self if isinstance(m, nn.BatchNorm2d)), None)
         return conv, norm
 
-    def forward_nhwc(self, x: Tensor) -> Tensor:
+    def forward_nhwc(self, x: Tensor, defer=None) -> Tensor:
+        """defer: an ops.DeferredAffine when the only consumer of the result is a blur-pool that takes the BatchNorm
+        affine over (AntialiasedDownscaler, BiFPNLayer)."""
         conv, bn = self._parts()
         if conv.groups != 1 or conv.padding_mode != "zeros":
             raise NotImplementedError("sihl_amd conv kernels cover groups=1, zero padding")
@@ -69,7 +71,7 @@ class _ConvBlock(nn.Sequential):
                 ops.bump_counter(bn.num_batches_tracked)
             y = ops.conv_block(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, stride=sh,
                                pad=ph, dil=dh, act=self.act, order=self.order, training=self.training, eps=bn.eps,
-                               momentum=bn.momentum)
+                               momentum=bn.momentum, defer=defer if cout % vec == 0 else None)
         else:
             y = ops.conv_block(x, weight, bias, None, None, None, None, stride=sh, pad=ph, dil=dh, act=self.act)
         return y if y.shape[-1] == cout else y[..., :cout]

@@ -74,8 +74,10 @@ class BiFPNLayer(nn.Module):
         # ascend: module k produces level k+1 from (blurred conv of level k, the input, the top-down map)
         out = [down[0]]
         for k in range(top):
-            pre = self.downscalers[k][0].forward_nhwc(out[k])  # conv; its blur is fused into the merge below
-            merged = ops.blur_fuse(pre, feats[k + 1], down[k + 1], self.down_fusions[k].weights)
+            # conv block of the downscaler; its blur - and in training its BatchNorm affine - is fused into the merge below
+            affine = ops.DeferredAffine()
+            pre = self.downscalers[k][0].forward_nhwc(out[k], defer=affine)
+            merged = ops.blur_fuse(pre, feats[k + 1], down[k + 1], self.down_fusions[k].weights, a_affine=affine)
             out.append(self.down_convs[k].forward_nhwc(merged))
         return out
 

@@ -21,10 +21,10 @@ class BlurPool2d(nn.Module):
         t = torch.tensor(taps.astype(np.float32))
         self.register_buffer("kernel", torch.outer(t, t)[None, None].repeat(in_channels, 1, 1, 1))
 
-    def forward_nhwc(self, x: Tensor) -> Tensor:
+    def forward_nhwc(self, x: Tensor, a_affine=None) -> Tensor:
         if self.kernel_size != 3 or self.stride != 2:
             raise NotImplementedError("HIP blur-pool covers kernel_size=3, stride=2 (the neck's downscaler)")
-        return ops.blur_fuse(x)
+        return ops.blur_fuse(x, a_affine=a_affine)
 
     def forward(self, x: Tensor) -> Tensor:
         return ops.nchw_view(self.forward_nhwc(ops.nhwc(x)))
@@ -36,7 +36,8 @@ class AntialiasedDownscaler(nn.Sequential):
                          BlurPool2d(out_channels, stride=2))
 
     def forward_nhwc(self, x: Tensor) -> Tensor:
-        return self[1].forward_nhwc(self[0].forward_nhwc(x))
+        affine = ops.DeferredAffine()  # training: the conv block's BatchNorm affine rides in the blur (one pass less)
+        return self[1].forward_nhwc(self[0].forward_nhwc(x, defer=affine), a_affine=affine)
 
     def forward(self, x: Tensor) -> Tensor:
         return ops.nchw_view(self.forward_nhwc(ops.nhwc(x)))

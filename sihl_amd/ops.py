@@ -567,7 +567,7 @@ class ConvBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, cfg, residual=None, hand_over=None,
-                take_over=None, dx_to=None):
+                take_over=None, dx_to=None, defer=None):
         stride, pad, dil, act, order, has_norm, training, eps, momentum, need_grad = cfg
         xd = x.detach()
         ctx.has_res = residual is not None
@@ -610,7 +610,13 @@ class ConvBlockFn(torch.autograd.Function):
                 ctx.save_for_backward(xd, w, s, mean, rstd, gamma.detach(), beta.detach(), y)
                 ctx.batch_stats, ctx.kind = True, "norm"
                 return y
-            y = affine_act(s, scale, shift, None if mode == 0 else act)
+            if defer is not None and mode == 0:
+                # the consumer (a blur-pool) applies y = s * scale + shift: hand s out in y's place (see DeferredAffine);
+                # the gradient that comes back is y's, as for any other consumer
+                defer.scale, defer.shift = scale, shift
+                y = s
+            else:
+                y = affine_act(s, scale, shift, None if mode == 0 else act)
             ctx.batch_stats = True
         else:
             scale, shift = bn_eval_affine(gamma, beta, running_mean, running_var, eps)
@@ -697,7 +703,24 @@ class ConvBlockFn(torch.autograd.Function):
                                            _stream())
             check(rc, "sihl_conv2d_dgrad")
         _guard_shared_parameters(ctx.pkeys)
-        return dx, dw, dbias, dgamma, dbeta, None, None, None, dres, None, None, None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, dres, None, None, None, None
+
+
+DEFER_BN_AFFINE = os.environ.get("SIHL_DEFER_BN_AFFINE", "1") != "0"  # A/B and test switch: False = every conv block applies its BatchNorm affine itself
+
+
+class DeferredAffine:
+    """Lets a training-mode conv -> act -> BatchNorm block leave its last step, y = s * scale + shift, to the ONE consumer
+    of y when that consumer is a blur-pool (the antialiased downscalers of the necks): the block returns the pre-norm
+    tensor s and fills ``scale`` / ``shift``; ``blur_fuse(.., a_affine=carrier)`` applies them to the blurred value.  One
+    launch and one read + write of the full-resolution tensor less per downscaler (the affine is linear and the blur taps
+    sum to 1, so the result is the same up to rounding).  Left empty (scale None) whenever the block applied the affine
+    itself (inference: folded into the conv epilogue)."""
+
+    __slots__ = ("scale", "shift")
+
+    def __init__(self):
+        self.scale = self.shift = None
 
 
 class GradCarrier:
@@ -734,8 +757,9 @@ def conv_block_into(out: Tensor, out_image_stride: int, x_nhwc, weight, bias, ga
 
 def conv_block(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, *, stride=1, pad=0, dil=1, act=None,
                order="act_norm", training=False, eps=1e-5, momentum=0.1, residual=None, hand_over=None,
-               take_over=None, dx_to=None):
+               take_over=None, dx_to=None, defer=None):
     """residual (optional, order "norm_act" only): the block computes relu(BN(conv(x)) + residual).
+    defer: a DeferredAffine - the caller promises that the ONLY consumer of the result is ``blur_fuse(.., a_affine=defer)``.
     hand_over / take_over: see GradCarrier (training only).  dx_to: carrier that receives this (1x1, pad 0) conv's
     input gradient in compact form - the projection shortcut of a residual block whose first conv was given the same
     carrier as take_over and reads the same x."""
@@ -754,6 +778,9 @@ def conv_block(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, *, 
             dx_to.expect = True
             return ConvBlockFn.apply(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, cfg, None, None,
                                      None, dx_to)
+        if defer is not None and DEFER_BN_AFFINE and has_norm and training and order == "act_norm":
+            return ConvBlockFn.apply(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, cfg, None, None, None,
+                                     None, defer)
         return ConvBlockFn.apply(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, cfg)
     if order != "norm_act" or not has_norm or act is not None:
         raise ValueError("residual merge is defined for conv -> BatchNorm (no activation) blocks")
@@ -799,10 +826,12 @@ class FuseUp2Fn(torch.autograd.Function):
 
 
 class BlurFuseFn(torch.autograd.Function):
-    """out = w0 * blurpool_s2(a) + w1 * b + w2 * c, or plain blurpool_s2(a) when b is None  (NHWC)."""
+    """out = w0 * blurpool_s2(a) + w1 * b + w2 * c, or plain blurpool_s2(a) when b is None  (NHWC).
+    a_scale / a_shift: ``a`` is the pre-norm output of a conv block that deferred its BatchNorm affine (DeferredAffine); the
+    gradient returned for it is that of ``a * scale + shift``, which is what the block's backward expects."""
 
     @staticmethod
-    def forward(ctx, a, b, c, wraw):
+    def forward(ctx, a, b, c, wraw, a_scale=None, a_shift=None):
         a = a.detach().contiguous()
         N, H, W, C = a.shape
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
@@ -812,28 +841,29 @@ class BlurFuseFn(torch.autograd.Function):
         else:
             wr = None
         out = torch.empty((N, Ho, Wo, C), dtype=a.dtype, device=a.device)
-        rc = _C.lib().sihl_blur_fuse(_p(a), _p(b), _p(c), _p(wr), _p(out), N, H, W, C, _dt(a), _stream())
+        rc = _C.lib().sihl_blur_fuse(_p(a), _p(b), _p(c), _p(wr), _p(a_scale), _p(a_shift), _p(out), N, H, W, C, _dt(a),
+                                     _stream())
         check(rc, "sihl_blur_fuse")
         ctx.fused = fused
-        ctx.save_for_backward(a, b, c, wr)
+        ctx.save_for_backward(a, b, c, wr, a_scale, a_shift)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        a, b, c, wr = ctx.saved_tensors
+        a, b, c, wr, a_scale, a_shift = ctx.saved_tensors
         dout = dout.contiguous()
         N, H, W, C = a.shape
-        need_a, need_b, need_c, need_w = ctx.needs_input_grad
+        need_a, need_b, need_c, need_w = ctx.needs_input_grad[:4]
         dev = a.device
         da = torch.empty_like(a) if need_a else None
         db = torch.empty_like(dout) if (ctx.fused and need_b) else None
         dc = torch.empty_like(dout) if (ctx.fused and need_c) else None
         dw = torch.empty(3, dtype=torch.float32, device=dev) if (ctx.fused and need_w) else None
         gacc = torch.empty(3, dtype=torch.float32, device=dev) if dw is not None else None
-        rc = _C.lib().sihl_blur_fuse_bwd(_p(dout), _p(a), _p(b), _p(c), _p(wr), _p(da), _p(db), _p(dc), _p(dw),
-                                         _p(gacc), N, H, W, C, _dt(a), _stream())
+        rc = _C.lib().sihl_blur_fuse_bwd(_p(dout), _p(a), _p(b), _p(c), _p(wr), _p(a_scale), _p(a_shift), _p(da), _p(db),
+                                         _p(dc), _p(dw), _p(gacc), N, H, W, C, _dt(a), _stream())
         check(rc, "sihl_blur_fuse_bwd")
-        return da, db, dc, dw
+        return da, db, dc, dw, None, None
 
 
 class Up2Fn(torch.autograd.Function):
@@ -963,7 +993,10 @@ def fuse_sum(wraw, xs):
     return FuseSumFn.apply(wraw, *xs)
 
 
-def blur_fuse(a, b=None, c=None, wraw=None):
+def blur_fuse(a, b=None, c=None, wraw=None, a_affine=None):
+    """a_affine: a DeferredAffine filled by the conv block that produced ``a`` (or None)."""
+    if a_affine is not None and a_affine.scale is not None:
+        return BlurFuseFn.apply(a, b, c, wraw, a_affine.scale, a_affine.shift)
     return BlurFuseFn.apply(a, b, c, wraw)
 
 

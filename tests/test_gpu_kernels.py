@@ -185,6 +185,79 @@ def test_fusion_nodes_borders_and_odd_sizes(dtype, rtol, atol):
         _close(plain.permute(0, 3, 1, 2), blur, rtol, atol, f"plain blur {N}x{H}x{W}x{C}")
 
 
+@pytest.mark.parametrize("dtype,rtol,atol", DTYPES)
+def test_blur_fuse_with_deferred_affine(dtype, rtol, atol):
+    """sihl_blur_fuse / _bwd with a_scale, a_shift (the training-mode BatchNorm affine of the downscaler's conv block,
+    layers/scalers.py:26-30 + convblocks.py:53-85, applied to the blurred value) against PyTorch computing
+    blur(a * scale + shift): forward, the gradient of the affine'd input (what ConvBlockFn.backward takes), both side
+    inputs and the fusion weights; fused and plain (b = c = None) forms, even and odd sizes."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(23)
+    k = torch.tensor([0.25, 0.5, 0.25])
+    k2 = torch.outer(k, k)
+    for (N, C, H, W, fused) in [(2, 32, 8, 12, True), (1, 64, 5, 7, True), (2, 32, 2, 2, True), (2, 32, 6, 10, False)]:
+        a = torch.randn(N, C, H, W, generator=g).to(dtype).float()
+        scale, shift = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+        y = (a * scale[None, :, None, None] + shift[None, :, None, None]).requires_grad_(True)  # the virtual BN output
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        blur = F.conv2d(F.pad(y, [1, 1, 1, 1], mode="reflect"), k2[None, None].repeat(C, 1, 1, 1), stride=2, groups=C)
+        mk = lambda t: t.detach().to(DEV, dtype).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+        aff = ops.DeferredAffine()
+        aff.scale, aff.shift = scale.to(DEV), shift.to(DEV)
+        ad = mk(a)
+        if fused:
+            b = torch.randn(N, C, Ho, Wo, generator=g).to(dtype).float().requires_grad_(True)
+            c = torch.randn(N, C, Ho, Wo, generator=g).to(dtype).float().requires_grad_(True)
+            wr = torch.randn(3, generator=g).requires_grad_(True)
+            sm = wr.softmax(0)
+            ref = sm[0] * blur + sm[1] * b + sm[2] * c
+            bd, cd, wd = mk(b), mk(c), wr.detach().to(DEV).requires_grad_(True)
+            out = ops.blur_fuse(ad, bd, cd, wd, a_affine=aff)
+        else:
+            ref = blur
+            out = ops.blur_fuse(ad, a_affine=aff)
+        cot = torch.randn(ref.shape, generator=g).to(dtype).float()
+        ref.backward(cot)
+        out.backward(cot.to(DEV, dtype).permute(0, 2, 3, 1).contiguous())
+        _close(out.permute(0, 3, 1, 2), ref, rtol, atol, "affine blur fwd")
+        _close(ad.grad.permute(0, 3, 1, 2), y.grad, rtol, atol, "affine blur d(a*scale+shift)")
+        if fused:
+            _close(bd.grad.permute(0, 3, 1, 2), b.grad, rtol, atol, "affine blur db")
+            _close(cd.grad.permute(0, 3, 1, 2), c.grad, rtol, atol, "affine blur dc")
+            _close(wd.grad, wr.grad, rtol * 5, atol * 5, "affine blur dw")
+
+
+def test_downscaler_deferred_affine_matches_plain_path():
+    """AntialiasedDownscaler in training mode (conv -> ReLU -> BatchNorm -> blur-pool): the BatchNorm affine folded into
+    the blur launch (ops.DEFER_BN_AFFINE, default) against the same module with the affine as a pass of its own - output,
+    input gradient, every parameter gradient and the running statistics (fp32, so only the summation order differs)."""
+    ops = _ops()
+    from sihl_amd.layers.scalers import AntialiasedDownscaler
+    torch.manual_seed(3)
+    mod = AntialiasedDownscaler(32, 32).to(DEV).train()
+    x0 = torch.randn(2, 32, 12, 10, device=DEV)
+    res = {}
+    state = {k_: v.clone() for k_, v in mod.state_dict().items()}
+    for defer in (True, False):
+        mod.load_state_dict(state)
+        mod.zero_grad(set_to_none=True)
+        ops.DEFER_BN_AFFINE = defer
+        try:
+            x = x0.clone().requires_grad_(True)
+            y = mod(x)
+            y.square().sum().backward()
+        finally:
+            ops.DEFER_BN_AFFINE = True
+        res[defer] = (y.detach(), x.grad, [p.grad for p in mod.parameters()], mod[0][2].running_mean.clone(),
+                      mod[0][2].running_var.clone())
+    _close(res[True][0], res[False][0], 1e-5, 1e-5, "downscaler output")
+    _close(res[True][1], res[False][1], 1e-4, 1e-4, "downscaler dx")
+    for ga, gb in zip(res[True][2], res[False][2]):
+        _close(ga, gb, 1e-4, 1e-4, "downscaler parameter gradient")
+    _close(res[True][3], res[False][3], 1e-6, 1e-6, "running mean")
+    _close(res[True][4], res[False][4], 1e-6, 1e-6, "running var")
+
+
 @pytest.mark.parametrize("stages", [2, 3, "rows"])
 def test_whole_mlp_one_launch(stages):
     """torchvision.ops.MLP as the dense heads use it ([Linear -> LayerNorm -> SiLU] x n -> Linear,
