@@ -135,8 +135,10 @@ int sihl_bn_eval_affine(const float* gamma, const float* beta, const float* runn
 /* y = act(x*scale[c] + shift[c]) over [rows][C] (norm-apply; stand-alone SiLU / sigmoid), and its input gradient. */
 int sihl_affine_act(const void* x, void* y, long rows, int C, const float* scale, const float* shift, int act,
                     int dtype, hipStream_t stream);
-/* y = act(x*scale[c] + shift[c] + res): BatchNorm-apply + residual add + activation of a ResNet block tail. */
-int sihl_affine_add_act(const void* x, const void* res, void* y, long rows, int C, const float* scale,
+/* y = act(x*scale[c] + shift[c] + res): BatchNorm-apply + residual add + activation of a ResNet block tail.
+ * mask (optional, bytes [rows * C / V], V = 8 bf16 / 4 fp32 elements per 16-byte vector): bit e of byte i = (element e of
+ * vector i of y > 0) - the ReLU mask for sihl_norm_add_relu_bwd, so the backward need not re-read y. */
+int sihl_affine_add_act(const void* x, const void* res, void* y, void* mask, long rows, int C, const float* scale,
                         const float* shift, int act, int dtype, hipStream_t stream);
 int sihl_affine_act_bwd(const void* x, const void* dy, void* dx, long rows, int C, const float* scale,
                         const float* shift, int act, int dtype, hipStream_t stream);
@@ -157,10 +159,12 @@ int sihl_norm_act_bwd(const void* s, const void* dy, void* dz, long rows, int C,
 
 /* Backward of a residual block's tail y = relu(BatchNorm(s) + identity) (torchvision Bottleneck / BasicBlock merge, wrapped
  * by src/sihl/torchvision_backbone.py): dres = dy * (y > 0) - the identity branch's gradient - and dz = BatchNorm backward
- * of dres, the ReLU mask applied inside the column reduction.  ws as for sihl_norm_act_bwd. */
-int sihl_norm_add_relu_bwd(const void* s, const void* dy, const void* y, void* dres, void* dz, long rows, int C,
-                           const float* mean, const float* rstd, const float* gamma, const float* beta, float* dgamma,
-                           float* dbeta, int batch_stats, int dtype, float* ws, long ws_bytes, hipStream_t stream);
+ * of dres, the ReLU mask applied inside the column reduction.  ws as for sihl_norm_act_bwd.
+ * The mask comes from `mask` (the bytes sihl_affine_add_act wrote) when given, else from y; one of the two may be NULL. */
+int sihl_norm_add_relu_bwd(const void* s, const void* dy, const void* y, const void* mask, void* dres, void* dz, long rows,
+                           int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                           float* dgamma, float* dbeta, int batch_stats, int dtype, float* ws, long ws_bytes,
+                           hipStream_t stream);
 
 /* ---- BiFPN fusion nodes, fused with their producer (layers/bifpn.py:10-17,39-53) --------------------------
  * w = softmax(wraw) exactly as FastNormalizedFusion (bifpn.py:16); wraw is the raw nn.Parameter (fp32).

@@ -55,13 +55,13 @@ SIGNATURES = {
     "sihl_bn_finalize": (I, [P, I, I, L, P, P, F, F, P, P, P, P, P, P, P]),
     "sihl_bn_eval_affine": (I, [P, P, P, P, F, I, P, P, P]),
     "sihl_affine_act": (I, [P, P, L, I, P, P, I, I, P]),
-    "sihl_affine_add_act": (I, [P, P, P, L, I, P, P, I, I, P]),
+    "sihl_affine_add_act": (I, [P, P, P, P, L, I, P, P, I, I, P]),
     "sihl_affine_act_bwd": (I, [P, P, P, L, I, P, P, I, I, P]),
     "sihl_bn_stats_rows": (I, [L, I, I]),
     "sihl_bn_stats": (I, [P, L, I, P, I, I, P]),
     "sihl_norm_act_bwd_ws_bytes": (L, [L, I, I]),
     "sihl_norm_act_bwd": (I, [P, P, P, L, I, P, P, P, P, P, P, I, I, I, I, P, L, P]),
-    "sihl_norm_add_relu_bwd": (I, [P, P, P, P, P, L, I, P, P, P, P, P, P, I, I, P, L, P]),
+    "sihl_norm_add_relu_bwd": (I, [P, P, P, P, P, P, L, I, P, P, P, P, P, P, I, I, P, L, P]),
     "sihl_fuse_up2": (I, [P, P, P, P, I, I, I, I, I, P]),
     "sihl_fuse_up2_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "sihl_nearest_up2_add": (I, [P, P, P, I, I, I, I, I, P]),

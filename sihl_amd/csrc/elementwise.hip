@@ -163,7 +163,7 @@ template <int ACT> __device__ __forceinline__ float act_grad_c(float v) {
 template <typename T, int ACT, bool FIXED>
 __global__ void affine_act_kernel(const T* __restrict__ x, T* __restrict__ y, long nvec, int cvec,
                                   const float* __restrict__ scale, const float* __restrict__ shift,
-                                  const T* __restrict__ res) {
+                                  const T* __restrict__ res, unsigned char* __restrict__ mask) {
   constexpr int V = 16 / sizeof(T);
   float sc[V], sh[V];
   const long i0 = (long)blockIdx.x * TPB + threadIdx.x;
@@ -172,6 +172,8 @@ __global__ void affine_act_kernel(const T* __restrict__ x, T* __restrict__ y, lo
     ldparam<V>(scale, c, sc, 1.f);
     ldparam<V>(scale ? shift : nullptr, c, sh, 0.f);
   }
+  // (a sweep from the tensor's END - the tail the producing conv left in the Infinity Cache first - was measured and
+  // changes nothing here: 15.29 vs 15.30 ms per 10 steps, profiles/r03_ew_order_ab.txt)
   for (long i = i0; i < nvec; i += (long)gridDim.x * TPB) {
     if (!FIXED) {
       const int c = (int)(i % cvec) * V;
@@ -185,6 +187,12 @@ __global__ void affine_act_kernel(const T* __restrict__ x, T* __restrict__ y, lo
       ldv(res + i * V, r);
 #pragma unroll
       for (int e = 0; e < V; ++e) f[e] = act_c<ACT>(f[e] * sc[e] + sh[e] + r[e]);
+      if (mask) {  // bit e = (output e > 0): the ReLU mask the block's backward needs, 1/16 of re-reading y for it
+        unsigned m = 0;
+#pragma unroll
+        for (int e = 0; e < V; ++e) m |= (f[e] > 0.f ? 1u : 0u) << e;
+        mask[i] = (unsigned char)m;
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < V; ++e) f[e] = act_c<ACT>(f[e] * sc[e] + sh[e]);
@@ -759,21 +767,33 @@ __global__ void fusion_wgrad_kernel(const float* wraw, const float* g, float* dw
 // mode 1: g = dy*act'(xhat*gamma+beta); sums of g and g*xhat   [norm -> act, s = pre-norm tensor]
 // Thread -> (channel vector cv, row lane rl): a block's rows are dealt to nrl = TPB/cvec row lanes, folded
 // through LDS into ONE partial row per block: part[block][2][C].
-// MASK (the tail of a residual block, y = relu(BN(s) + identity)): the incoming gradient is first masked by y > 0 - the
+// MASK 1 / 2 (the tail of a residual block, y = relu(BN(s) + identity)): the incoming gradient is first masked by y > 0
+// (1: read from y; 2: from the byte-per-vector mask the forward wrote - a sixteenth of y's bytes) - the
 // gradient of both merge inputs, written to `dres` for the identity branch and for the apply pass - in the SAME pass that
 // folds it into the column sums: one kernel and 4 tensor passes (s, dy, y read; dres written) where a separate ReLU
 // backward + this reduction took 5.
-template <typename T, int MODE, int ACT, bool MASK = false>
+template <typename T, int MODE, int ACT, int MASK = 0>
 __global__ void norm_bwd_reduce_kernel(const T* __restrict__ s, const T* __restrict__ dy, long rows, int C,
                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                       float* __restrict__ part, int rows_per_block, int nrl,
-                                       const T* __restrict__ ymask = nullptr, T* __restrict__ dres = nullptr) {
+                                       float* __restrict__ part, int rows_per_block, int nrl, int rev,
+                                       const void* __restrict__ ymask = nullptr, T* __restrict__ dres = nullptr) {
   constexpr int V = 16 / sizeof(T);
   const int cvec = C / V;
-  const long r0 = (long)blockIdx.x * rows_per_block;
-  const long r1 = min(rows, r0 + rows_per_block);
+  // rows of a workgroup: a contiguous range (rev 0), or - rev - row lanes dealt round by round over the whole grid and
+  // walked from the tensor's END to its start.  All workgroups are resident together, so with contiguous ranges what is
+  // left in the 256 MB Infinity Cache at the end is a stripe of every range; walked in descending rounds the pass ends on
+  // the HEAD of s and dy, which is where the apply pass (ascending rounds) starts: its first 64 - 128 MB per tensor are
+  // then served on-die.  (Deterministic either way: a workgroup's rows and their order are fixed by the launch.)
   const int rl = threadIdx.x / cvec;
+  long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block), rstep = nrl;
+  if (rev) {
+    const long round = (long)gridDim.x * nrl;
+    r0 = (long)blockIdx.x * nrl;                                      // first round's row of lane 0
+    r0 = r0 + rl < rows ? r0 + (rows - 1 - r0 - rl) / round * round : rows;  // last round holding a row for this lane
+    r1 = rows;
+    rstep = -round;
+  }
   extern __shared__ float red_lds[];  // [nrl][2][C]
   for (int cv = threadIdx.x % cvec; cv < cvec && rl < nrl; cv += TPB) {
     float sb[V], sg[V];
@@ -784,15 +804,20 @@ __global__ void norm_bwd_reduce_kernel(const T* __restrict__ s, const T* __restr
     ldparam<V>(rstd, cv * V, rs, 1.f);
     ldparam<V>(MODE == 1 ? gamma : nullptr, cv * V, ga, 1.f);
     ldparam<V>(MODE == 1 ? beta : nullptr, cv * V, be, 0.f);
-    for (long r = r0 + rl; r < r1; r += nrl) {
+    for (long r = r0 + rl; r >= 0 && r < r1; r += rstep) {
       float fs[V], fd[V];
       ldv(s + (r * cvec + cv) * V, fs);
       ldv(dy + (r * cvec + cv) * V, fd);
-      if (MASK) {
+      if (MASK == 1) {  // mask from the block's output y
         float fy[V];
-        ldv(ymask + (r * cvec + cv) * V, fy);
+        ldv((const T*)ymask + (r * cvec + cv) * V, fy);
 #pragma unroll
         for (int e = 0; e < V; ++e) fd[e] = fy[e] > 0.f ? fd[e] : 0.f;
+        stv(dres + (r * cvec + cv) * V, fd);
+      } else if (MASK == 2) {  // mask bits written by the forward (sihl_affine_add_act): a byte per vector
+        const unsigned m = ((const unsigned char*)ymask)[r * cvec + cv];
+#pragma unroll
+        for (int e = 0; e < V; ++e) fd[e] = ((m >> e) & 1u) ? fd[e] : 0.f;
         stv(dres + (r * cvec + cv) * V, fd);
       }
 #pragma unroll
@@ -1311,11 +1336,19 @@ __global__ void maxpool3x3s2_bwd_kernel(const T* __restrict__ dy, const unsigned
 
 }  // namespace
 
-#define SIHL_AFF(A, F) hipLaunchKernelGGL((affine_act_kernel<T, A, F>), dim3(g), dim3(TPB), 0, stream, (const T*)x, (T*)y, nvec, C / V, scale, shift, (const T*)res)
+// sweep order of norm_bwd_reduce (bit 1 set: descending rounds, the default; SIHL_EW_ORDER=0 for the A/B:
+// profiles/r03_ew_order_ab.txt)
+static int ew_order() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("SIHL_EW_ORDER"); v = e ? atoi(e) : 2; }
+  return v;
+}
+
+#define SIHL_AFF(A, F) hipLaunchKernelGGL((affine_act_kernel<T, A, F>), dim3(g), dim3(TPB), 0, stream, (const T*)x, (T*)y, nvec, C / V, scale, shift, (const T*)res, (unsigned char*)mask)
 #define SIHL_AFF_A(A) do { if (fixed) SIHL_AFF(A, true); else SIHL_AFF(A, false); } while (0)
 #define SIHL_AFB(A, F) hipLaunchKernelGGL((affine_act_bwd_kernel<T, A, F>), dim3(g), dim3(TPB), 0, stream, (const T*)x, (const T*)dy, (T*)dx, nvec, C / V, scale, shift)
 #define SIHL_AFB_A(A) do { if (fixed) SIHL_AFB(A, true); else SIHL_AFB(A, false); } while (0)
-#define SIHL_NBR(M, A) hipLaunchKernelGGL((norm_bwd_reduce_kernel<T, M, A>), dim3(nblk), dim3(TPB), red_lds, stream, (const T*)s, (const T*)dy, rows, C, mean, rstd, gamma, beta, ws, rpb, nrl)
+#define SIHL_NBR(M, A) hipLaunchKernelGGL((norm_bwd_reduce_kernel<T, M, A>), dim3(nblk), dim3(TPB), red_lds, stream, (const T*)s, (const T*)dy, rows, C, mean, rstd, gamma, beta, ws, rpb, nrl, (ew_order() >> 1) & 1)
 #define SIHL_NBA(M, A, F) hipLaunchKernelGGL((norm_bwd_apply_kernel<T, M, A, F>), dim3(g), dim3(TPB), 0, stream, (const T*)s, (const T*)dy, (T*)dz, nvec, C / V, mean, rstd, gamma, beta, (const float*)s0, (const float*)s1, 1.f / (float)rows, batch_stats)
 #define SIHL_NBA_F(M, A) do { if (fixed) SIHL_NBA(M, A, true); else SIHL_NBA(M, A, false); } while (0)
 
@@ -1351,18 +1384,19 @@ int sihl_bn_eval_affine(const float* gamma, const float* beta, const float* runn
   return SIHL_OK;
 }
 
-int sihl_affine_add_act(const void* x, const void* res, void* y, long rows, int C, const float* scale,
+int sihl_affine_add_act(const void* x, const void* res, void* y, void* mask, long rows, int C, const float* scale,
                         const float* shift, int act, int dtype, hipStream_t stream);
 
 int sihl_affine_act(const void* x, void* y, long rows, int C, const float* scale, const float* shift, int act,
                     int dtype, hipStream_t stream) {
-  return sihl_affine_add_act(x, nullptr, y, rows, C, scale, shift, act, dtype, stream);
+  return sihl_affine_add_act(x, nullptr, y, nullptr, rows, C, scale, shift, act, dtype, stream);
 }
 
-// y = act(x*scale[c] + shift[c] + res): BatchNorm-apply + residual add + activation in one pass (res may be NULL)
-int sihl_affine_add_act(const void* x, const void* res, void* y, long rows, int C, const float* scale,
+// y = act(x*scale[c] + shift[c] + res): BatchNorm-apply + residual add + activation in one pass (res may be NULL).
+// mask (optional, with res): one byte per 16-byte vector of y, bit e = (y element e > 0) - for sihl_norm_add_relu_bwd
+int sihl_affine_add_act(const void* x, const void* res, void* y, void* mask, long rows, int C, const float* scale,
                         const float* shift, int act, int dtype, hipStream_t stream) {
-  if (!x || !y || rows <= 0 || C <= 0) return SIHL_EARG;
+  if (!x || !y || rows <= 0 || C <= 0 || (mask && !res)) return SIHL_EARG;
   DISPATCH_DTYPE(dtype, {
     constexpr int V = 16 / sizeof(T);
     if (C % V) return SIHL_EARG;
@@ -1668,10 +1702,11 @@ int sihl_bn_stats(const void* x, long rows, int C, float* partials, int n_partia
 // Backward of a residual block's tail  y = relu(BN(s) + identity)  (conv -> BatchNorm, no activation of its own, mode 1):
 // dres = dy * (y > 0) (the gradient of the identity branch AND of BN's output), dz = BN backward of dres.  The mask is
 // applied inside the column reduction (norm_bwd_reduce_kernel<.., MASK>), not in a pass of its own.
-int sihl_norm_add_relu_bwd(const void* s, const void* dy, const void* y, void* dres, void* dz, long rows, int C,
-                           const float* mean, const float* rstd, const float* gamma, const float* beta, float* dgamma,
-                           float* dbeta, int batch_stats, int dtype, float* ws, long ws_bytes, hipStream_t stream) {
-  if (!s || !dy || !y || !dres || !dz || rows <= 0 || C <= 0 || !mean || !rstd || !ws) return SIHL_EARG;
+int sihl_norm_add_relu_bwd(const void* s, const void* dy, const void* y, const void* mask, void* dres, void* dz, long rows,
+                           int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                           float* dgamma, float* dbeta, int batch_stats, int dtype, float* ws, long ws_bytes,
+                           hipStream_t stream) {
+  if (!s || !dy || (!y && !mask) || !dres || !dz || rows <= 0 || C <= 0 || !mean || !rstd || !ws) return SIHL_EARG;
   const int nrl = row_lanes(C / (dtype == SIHL_BF16 ? 8 : 4));
   const int nblk = reduce_blocks(rows, nrl);
   if (ws_bytes < sihl_norm_act_bwd_ws_bytes(rows, C, dtype)) return SIHL_EWS;
@@ -1683,8 +1718,14 @@ int sihl_norm_add_relu_bwd(const void* s, const void* dy, const void* y, void* d
     constexpr int V = 16 / sizeof(T);
     if (C % V) return SIHL_EARG;
     const size_t red_lds = (size_t)nrl * 2 * C * sizeof(float);
-    hipLaunchKernelGGL((norm_bwd_reduce_kernel<T, 1, SIHL_ACT_NONE, true>), dim3(nblk), dim3(TPB), red_lds, stream,
-                       (const T*)s, (const T*)dy, rows, C, mean, rstd, gamma, beta, ws, rpb, nrl, (const T*)y, (T*)dres);
+    if (mask)
+      hipLaunchKernelGGL((norm_bwd_reduce_kernel<T, 1, SIHL_ACT_NONE, 2>), dim3(nblk), dim3(TPB), red_lds, stream,
+                         (const T*)s, (const T*)dy, rows, C, mean, rstd, gamma, beta, ws, rpb, nrl, (ew_order() >> 1) & 1,
+                         mask, (T*)dres);
+    else
+      hipLaunchKernelGGL((norm_bwd_reduce_kernel<T, 1, SIHL_ACT_NONE, 1>), dim3(nblk), dim3(TPB), red_lds, stream,
+                         (const T*)s, (const T*)dy, rows, C, mean, rstd, gamma, beta, ws, rpb, nrl, (ew_order() >> 1) & 1,
+                         y, (T*)dres);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, stream, (const float*)ws, nblk, 2, C, s0,
                        s1);
     const long nvec = rows * (C / V);

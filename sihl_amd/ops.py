@@ -61,6 +61,7 @@ def _sized(name: str, *args):
     return v
 
 _SPLIT_TAIL_BWD = bool(os.environ.get("SIHL_SPLIT_TAIL_BWD"))
+TAIL_MASK_BITS = os.environ.get("SIHL_TAIL_MASK_BITS", "1") != "0"  # A/B / test switch: 0 = the tail's backward re-reads y
 
 # ---- BatchNorm step counters: one multi-tensor add per training step instead of one tiny kernel per layer
 _DEFERRED_COUNTERS = None
@@ -452,13 +453,16 @@ def affine_act(x: Tensor, scale, shift, act) -> Tensor:
     return y
 
 
-def affine_add_act(x: Tensor, res: Tensor, scale, shift, act) -> Tensor:
+def affine_add_act(x: Tensor, res: Tensor, scale, shift, act, want_mask: bool = False):
+    """y = act(x * scale + shift + res).  want_mask: also return the (y > 0) bits, one byte per 16-byte vector of y (the
+    residual tail's backward reads them instead of y)."""
     C = x.shape[-1]
     y = torch.empty_like(x)
-    rc = _C.lib().sihl_affine_add_act(_p(x), _p(res), _p(y), x.numel() // C, C, _p(scale), _p(shift), ACT[act],
+    mask = torch.empty(x.numel() * x.element_size() // 16, dtype=torch.uint8, device=x.device) if want_mask else None
+    rc = _C.lib().sihl_affine_add_act(_p(x), _p(res), _p(y), _p(mask), x.numel() // C, C, _p(scale), _p(shift), ACT[act],
                                       _dt(x), _stream())
     check(rc, "sihl_affine_add_act")
-    return y
+    return (y, mask) if want_mask else y
 
 
 def affine_act_bwd(x: Tensor, dy: Tensor, scale, shift, act) -> Tensor:
@@ -484,9 +488,10 @@ def norm_act_bwd(s: Tensor, dy: Tensor, mean, rstd, gamma, beta, mode: int, act,
     return dz, dgamma, dbeta
 
 
-def norm_add_relu_bwd(s: Tensor, dy: Tensor, y: Tensor, mean, rstd, gamma, beta, batch_stats: bool):
+def norm_add_relu_bwd(s: Tensor, dy: Tensor, y, mean, rstd, gamma, beta, batch_stats: bool, mask=None):
     """Backward of y = relu(BN(s) + identity): (dres, dz, dgamma, dbeta) with the ReLU mask applied inside the reduction
-    pass (sihl_norm_add_relu_bwd) instead of a pass of its own."""
+    pass (sihl_norm_add_relu_bwd) instead of a pass of its own.  The mask is read from ``mask`` (affine_add_act's bytes)
+    when given, else from ``y``."""
     C = s.shape[-1]
     rows = s.numel() // C
     lib = _C.lib()
@@ -494,7 +499,7 @@ def norm_add_relu_bwd(s: Tensor, dy: Tensor, y: Tensor, mean, rstd, gamma, beta,
     dres, dz = torch.empty_like(s), torch.empty_like(s)
     dgamma = torch.empty(C, dtype=torch.float32, device=s.device)
     dbeta = torch.empty_like(dgamma)
-    rc = lib.sihl_norm_add_relu_bwd(_p(s), _p(dy), _p(y), _p(dres), _p(dz), rows, C, _p(mean), _p(rstd), _p(gamma),
+    rc = lib.sihl_norm_add_relu_bwd(_p(s), _p(dy), _p(y), _p(mask), _p(dres), _p(dz), rows, C, _p(mean), _p(rstd), _p(gamma),
                                     _p(beta), _p(dgamma), _p(dbeta), int(batch_stats), _dt(s), _p(ws), ws.numel(), _stream())
     check(rc, "sihl_norm_add_relu_bwd")
     return dres, dz, dgamma, dbeta
@@ -606,8 +611,13 @@ class ConvBlockFn(torch.autograd.Function):
             mean, rstd, scale, shift = bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean,
                                                    running_var)
             if residual is not None:  # block tail: y = relu(BN(conv) + identity) in one pass; keep y for the mask
-                y = affine_add_act(s, residual.detach().contiguous(), scale, shift, "relu")
-                ctx.save_for_backward(xd, w, s, mean, rstd, gamma.detach(), beta.detach(), y)
+                # the backward's ReLU mask: bits written here (1/16 of y's bytes) unless the A/B switch asks for y itself
+                if need_grad and not _SPLIT_TAIL_BWD and TAIL_MASK_BITS:
+                    y, bits = affine_add_act(s, residual.detach().contiguous(), scale, shift, "relu", want_mask=True)
+                else:
+                    y, bits = affine_add_act(s, residual.detach().contiguous(), scale, shift, "relu"), None
+                ctx.tail_bits = bits is not None
+                ctx.save_for_backward(xd, w, s, mean, rstd, gamma.detach(), beta.detach(), bits if bits is not None else y)
                 ctx.batch_stats, ctx.kind = True, "norm"
                 return y
             if defer is not None and mode == 0:
@@ -651,7 +661,10 @@ class ConvBlockFn(torch.autograd.Function):
                 dres = affine_act_bwd(y, dy, None, None, "relu")
                 dz, dgamma, dbeta = norm_act_bwd(s, dres, mean, rstd, gamma, beta, 1, None, ctx.batch_stats)
             else:
-                dres, dz, dgamma, dbeta = norm_add_relu_bwd(s, dy, y, mean, rstd, gamma, beta, ctx.batch_stats)
+                if ctx.tail_bits:
+                    dres, dz, dgamma, dbeta = norm_add_relu_bwd(s, dy, None, mean, rstd, gamma, beta, ctx.batch_stats, mask=y)
+                else:
+                    dres, dz, dgamma, dbeta = norm_add_relu_bwd(s, dy, y, mean, rstd, gamma, beta, ctx.batch_stats)
             if ctx.hand_over is not None:
                 ctx.hand_over.tensor, dres = dres, None
         elif ctx.kind == "norm":

@@ -258,6 +258,34 @@ def test_downscaler_deferred_affine_matches_plain_path():
     _close(res[True][4], res[False][4], 1e-6, 1e-6, "running var")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_residual_tail_mask_bits(dtype):
+    """Tail of a residual block, y = relu(BN(s) + identity) (torchvision Bottleneck merge behind
+    torchvision_backbone.py:42-49): sihl_affine_add_act's mask bytes hold exactly (y > 0), and
+    sihl_norm_add_relu_bwd gives the same dres / dz / dgamma / dbeta - bit for bit - from the bytes as from y itself;
+    dres against PyTorch's relu backward.  Ragged row counts, 64 - 2048 channels."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    for rows, C in [(1000, 64), (4096 + 37, 256), (300, 2048), (17, 32)]:
+        s = torch.randn(rows, C, generator=g).to(DEV, dtype)
+        ident = torch.randn(rows, C, generator=g).to(DEV, dtype)
+        dy = torch.randn(rows, C, generator=g).to(DEV, dtype)
+        scale, shift = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+        gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+        mean, rstd = torch.randn(C, generator=g).to(DEV) * 0.1, (torch.rand(C, generator=g) + 0.5).to(DEV)
+        y_plain = ops.affine_add_act(s, ident, scale, shift, "relu")
+        y, bits = ops.affine_add_act(s, ident, scale, shift, "relu", want_mask=True)
+        assert torch.equal(y, y_plain)
+        V = 16 // s.element_size()
+        want = ((y.reshape(-1, V) > 0).to(torch.int32) << torch.arange(V, device=DEV, dtype=torch.int32)).sum(1)
+        assert torch.equal(bits.to(torch.int32), want), "mask bytes"
+        from_y = ops.norm_add_relu_bwd(s, dy, y, mean, rstd, gamma, beta, True)
+        from_bits = ops.norm_add_relu_bwd(s, dy, None, mean, rstd, gamma, beta, True, mask=bits)
+        for a, b, nm in zip(from_bits, from_y, ("dres", "dz", "dgamma", "dbeta")):
+            assert torch.equal(a, b), nm
+        _close(from_bits[0], dy.float() * (y > 0), 0, 0, "dres")
+
+
 @pytest.mark.parametrize("stages", [2, 3, "rows"])
 def test_whole_mlp_one_launch(stages):
     """torchvision.ops.MLP as the dense heads use it ([Linear -> LayerNorm -> SiLU] x n -> Linear,
