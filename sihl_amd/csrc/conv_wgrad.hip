@@ -199,15 +199,19 @@ constexpr int WB = 256;        // channels per panel side
 constexpr int WKP = 64;        // pixels per stage
 constexpr int WROW = WB * 2;   // bytes per pixel row in LDS
 
-__global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(const WgradParams p) {
+// NW waves: 8 (2 x 4, each 128 co x 64 ci) or 16 (4 x 4, each 64 co x 64 ci: four waves per SIMD cover each other's
+// DMA-issue and barrier phases, as in the 256 x 256 forward tile; half the DMA pieces per wave).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void conv_wgrad_dma_kernel(const WgradParams p) {
   constexpr int TILE = WKP * WROW, STAGE = 2 * TILE;  // 32 KiB per operand, 64 KiB per stage
-  constexpr int NP = TILE / 1024 / 8;                 // DMA pieces per wave per operand per stage (= 4)
+  constexpr int NP = TILE / 1024 / NW;                // DMA pieces per wave per operand per stage (4 / 2)
+  constexpr int MI = 32 / NW;                         // 32-row co tiles per wave (4 / 2)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves, each 128 co x 64 ci
+  const int wm = wave >> 2, wn = wave & 3;  // (NW / 4) x 4 waves, each MI * 32 co x 64 ci
   const int ntaps = p.KH * p.KW;
   // Block -> (group, tap) with the taps of one (co panel, ci panel, K-split) group on ONE XCD and adjacent in
   // dispatch order (blocks b and b+8 share an XCD): they stream the same pixels at about the same time, so
@@ -266,9 +270,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(const WgradParams p
     if (s_oy[j] >= p.Ho) { s_oy[j] -= p.Ho; s_n[j] += 1; }
   };
 
-  f32x16_t acc[4][2];
+  f32x16_t acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -290,12 +294,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(const WgradParams p
     // operand fragments are double-buffered in registers: the transposed reads of k-step ks+1 are in flight while
     // k-step ks multiplies (reading and multiplying back to back left the matrix pipe idle for an LDS round trip
     // per k-step)
-    bf16x8_t a[2][4], bq[2][2];
+    bf16x8_t a[2][MI], bq[2][2];
     auto load_frags = [&](int ks, int slot) {
       const int row = ks * 16 + rowsel;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int off = tr_addr(row, (wm * 128 + t * 32) * 2);
+      for (int t = 0; t < MI; ++t) {
+        const int off = tr_addr(row, (wm * (MI * 32) + t * 32) * 2);
         s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(As + off));
         s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(As + off + 4 * WROW));
         a[slot][t] = __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(const WgradParams p
     for (int ks = 0; ks < WKP / 16; ++ks) {
       if (ks + 1 < WKP / 16) load_frags(ks + 1, (ks + 1) & 1);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], bq[ks & 1][j], acc[i][j], 0, 0, 0);
@@ -344,13 +348,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(const WgradParams p
 
   const int half = lane >> 5;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int ci = ci0 + wn * 64 + j * 32 + (lane & 31);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = co0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int co = co0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (co < p.Cout && ci < p.Cin)
           p.ws[(((long)split * p.Cout + co) * ntaps + tap) * p.Cin + ci] = acc[i][j][r];
       }
@@ -606,9 +610,14 @@ WgradPlan plan_wgrad(long M, int N, int H, int W, int Cin, int Cout, int KH, int
 int launch_dma(WgradParams p, hipStream_t stream) {
   constexpr int LDS = 2 * 2 * WKP * WROW;  // 128 KiB
   static bool attr_set = false;
+  static int nw = 16;  // SIHL_WGRAD_WAVES=8: the 8-wave form (A/B)
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    const char* env = getenv("SIHL_WGRAD_WAVES");
+    if (env && atoi(env) == 8) nw = 8;
     attr_set = true;
   }
   const int ngroups = p.tiles_co * p.tiles_ci * p.splits;
@@ -616,7 +625,8 @@ int launch_dma(WgradParams p, hipStream_t stream) {
   const double flops = 2.0 * p.M * (double)p.Cout * p.KH * p.KW * p.Cin;
   const double bytes = ((double)p.N * p.H * p.W * p.Cin + (double)p.M * p.Cout) * 2 + (double)p.Cout * p.KH * p.KW * p.Cin * 4.0;
   sihl_prof_begin(SIHL_PROF_WGRAD, SIHL_BF16, flops, bytes, stream);
-  hipLaunchKernelGGL(conv_wgrad_dma_kernel, dim3(grid), dim3(512), LDS, stream, p);
+  if (nw == 16) hipLaunchKernelGGL(conv_wgrad_dma_kernel<16>, dim3(grid), dim3(1024), LDS, stream, p);
+  else hipLaunchKernelGGL(conv_wgrad_dma_kernel<8>, dim3(grid), dim3(512), LDS, stream, p);
   sihl_prof_end(stream);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
