@@ -143,6 +143,18 @@ int sihl_affine_add_act(const void* x, const void* res, void* y, void* mask, lon
 int sihl_affine_act_bwd(const void* x, const void* dy, void* dx, long rows, int C, const float* scale,
                         const float* shift, int act, int dtype, hipStream_t stream);
 
+/* The ResNet stem: conv 7x7 / stride 2 / pad 3 of a 3-channel image into 64 channels (torchvision resnet.py conv1, wrapped
+ * by src/sihl/torchvision_backbone.py:42-49), bf16 on the matrix cores (csrc/stem.hip).  x: [N][3][H][W] fp32 or bf16 with
+ * the given element strides (any layout), H and W even; w: the fp32 master weights [64][3][7][7] with their element strides.
+ * xp (sihl_stem_xp_bytes bytes): receives the zero-padded NHWC bf16 copy of the image the kernel reads - keep it for the
+ * weight gradient; wp: 64 * 7 * 32 * 2 bytes of scratch for the packed weights.  out: [N][H/2][W/2][64] bf16.
+ * stats (optional): [sihl_stem_stats_rows(N, H)][2][64] fp32 partial sums / sums of squares of `out` for sihl_bn_finalize. */
+long sihl_stem_xp_bytes(int N, int H, int W);
+int sihl_stem_stats_rows(int N, int H);
+int sihl_stem_conv_fwd(const void* x, int x_dtype, long xsn, long xsc, long xsh, long xsw, const float* w, long wso, long wsc,
+                       long wsh, long wsw, void* xp, void* wp, void* out, float* stats, int N, int H, int W,
+                       hipStream_t stream);
+
 /* Batch statistics of an NHWC tensor another kernel produced (the ResNet stem's MIOpen conv): per-channel (sum, sumsq)
  * partial rows [sihl_bn_stats_rows(...)][2][C] in the layout sihl_bn_finalize reads (torchvision resnet.py stem:
  * conv1 -> bn1 -> relu, wrapped by src/sihl/torchvision_backbone.py:42-49). */

@@ -146,6 +146,13 @@ class _Trunk(nn.Module):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
     def forward(self, x: Tensor, n_taps: int, native: bool = False) -> List[Tensor]:
+        if native and ops.stem_supported(x, self.conv1, self.bn1) \
+                and (self.maxpool.kernel_size, self.maxpool.stride, self.maxpool.padding) == (3, 2, 1):
+            # bf16: the whole stem on the sihl kernels (conv1 on csrc/stem.hip, statistics from its epilogue)
+            stem = ops.stem_conv_bn_act(x, self.conv1, self.bn1, "relu")
+            taps = [ops.nchw_view(stem)]
+            y = ops.maxpool3x3s2(stem)
+            return self._stages(y, taps, n_taps, native)
         z = self.conv1(x)
         vec = 8 if z.dtype == torch.bfloat16 else 4
         if native and self.bn1.training and torch.is_grad_enabled() and z.is_cuda and z.dtype in (torch.bfloat16, torch.float32) \
@@ -165,6 +172,9 @@ class _Trunk(nn.Module):
             y = self.maxpool(taps[0])
             if native:
                 y = ops.nhwc(y)
+        return self._stages(y, taps, n_taps, native)
+
+    def _stages(self, y: Tensor, taps: List[Tensor], n_taps: int, native: bool) -> List[Tensor]:
         for i in range(1, 5):
             if len(taps) >= n_taps:
                 break

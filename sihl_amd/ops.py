@@ -556,6 +556,70 @@ class BNActFn(torch.autograd.Function):
         return (dz if ctx.needs_input_grad[0] else None), dgamma, dbeta, None, None, None, None, None
 
 
+class StemFn(torch.autograd.Function):
+    """The ResNet stem conv1 -> bn1 -> relu (torchvision resnet.py, behind src/sihl/torchvision_backbone.py:42-49) in bf16:
+    the 7x7 / stride 2 conv over 3 channels on ``sihl_stem_conv_fwd`` (csrc/stem.hip: the image packed once into a padded
+    NHWC bf16 copy, kernel rows as 32-element K segments), its batch statistics from the conv's own epilogue, then the
+    finalize / normalise / backward kernels of the fused conv block.  NCHW image in, NHWC activation out.  The weight
+    gradient runs on ATen's convolution_backward (MIOpen) over the packed image."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, eps, momentum, act, training):
+        xd, wd = x.detach(), weight.detach()
+        N, _, H, W = xd.shape
+        lib = _C.lib()
+        xp = torch.empty(_sized("sihl_stem_xp_bytes", N, H, W) // 2, dtype=torch.bfloat16, device=xd.device)
+        wp = torch.empty(64 * 7 * 32, dtype=torch.bfloat16, device=xd.device)
+        s = torch.empty((N, H // 2, W // 2, 64), dtype=torch.bfloat16, device=xd.device)
+        stats = torch.empty((_sized("sihl_stem_stats_rows", N, H), 2, 64), dtype=torch.float32, device=xd.device) \
+            if training else None
+        rc = lib.sihl_stem_conv_fwd(_p(xd), _dt(xd), *xd.stride(), _p(wd), *wd.stride(), _p(xp), _p(wp), _p(s), _p(stats),
+                                    N, H, W, _stream())
+        check(rc, "sihl_stem_conv_fwd")
+        if training:
+            mean, rstd, scale, shift = bn_finalize(stats, s.numel() // 64, gamma, beta, eps, momentum, running_mean, running_var)
+        else:
+            scale, shift = bn_eval_affine(gamma, beta, running_mean, running_var, eps)
+            mean, rstd = running_mean.detach().clone(), torch.rsqrt(running_var.detach() + eps)
+        y = affine_act(s, scale, shift, act)
+        ctx.save_for_backward(xp, s, mean, rstd, gamma.detach(), beta.detach(), wd)
+        ctx.act, ctx.training, ctx.shape = act, training, (N, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, s, mean, rstd, gamma, beta, w = ctx.saved_tensors
+        N, H, W = ctx.shape
+        dz, dgamma, dbeta = norm_act_bwd(s, dy.contiguous(), mean, rstd, gamma, beta, 1, ctx.act, ctx.training)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            Wp = xp.numel() // (N * (H + 6) * 3)
+            x_img = xp.view(N, H + 6, Wp, 3)[:, 3:3 + H, 4:4 + W, :].permute(0, 3, 1, 2)  # the image, bf16, NCHW view
+            dw = torch.ops.aten.convolution_backward(nchw_view(dz), x_img, w.to(torch.bfloat16), None, [2, 2], [3, 3], [1, 1],
+                                                     False, [0, 0], 1, [False, True, False])[1].float()
+        return None, dw, dgamma, dbeta, None, None, None, None, None, None
+
+
+def stem_supported(x: Tensor, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d) -> bool:
+    """The native stem covers torchvision's conv1 (3 -> 64, 7x7, stride 2, pad 3, no bias) on an even-sized CUDA image
+    that needs no gradient, computed in bf16 (autocast), with a default BatchNorm2d behind it."""
+    return (x.is_cuda and x.dim() == 4 and x.shape[1] == 3 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+            and x.dtype in (torch.float32, torch.bfloat16) and not x.requires_grad
+            and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16))
+            and tuple(conv.weight.shape) == (64, 3, 7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and conv.weight.dtype == torch.float32
+            and bn.momentum is not None and bn.track_running_stats and bn.affine
+            and not os.environ.get("SIHL_ATEN_STEM"))  # env: A/B switch
+
+
+def stem_conv_bn_act(x: Tensor, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, act: Optional[str]) -> Tensor:
+    """conv1 -> bn1 -> act of the ResNet stem (see StemFn); updates bn's running statistics in training mode."""
+    if bn.training:
+        bump_counter(bn.num_batches_tracked)
+    return StemFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, act,
+                        bn.training)
+
+
 def bn_act_train(s_nhwc: Tensor, bn: torch.nn.BatchNorm2d, act: Optional[str]) -> Tensor:
     """Training-mode BatchNorm2d (+ activation) of an NHWC tensor through the sihl kernels; updates bn's running
     statistics and step counter like nn.BatchNorm2d."""

@@ -86,3 +86,87 @@ def test_native_backbone_bf16_close():
     for lvl in range(1, 6):
         a, b = out[lvl].float(), ref[lvl]
         assert float((a - b).abs().max() / b.abs().max()) < 6e-2, lvl
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64), (1, 130, 70), (3, 96, 256), (2, 34, 514)])
+@pytest.mark.parametrize("xdtype", [torch.float32, torch.bfloat16])
+def test_stem_conv_kernel_matches_torch(shape, xdtype):
+    """sihl_stem_conv_fwd (conv1 of torchvision's ResNet behind torchvision_backbone.py:42-49: 7x7 / stride 2 / pad 3,
+    3 -> 64 channels, bf16 on the matrix cores from a packed copy of the image) against an fp32 conv2d of the same
+    bf16-rounded image and weights, and its epilogue statistics against the sums of its own output.  Output widths that
+    are not multiples of the 64-pixel chunk, fewer rows than a workgroup takes, images wider than high, fp32 and bf16
+    images, a channels-last image (strides)."""
+    import torch.nn.functional as F
+    from sihl_amd import _C, ops
+
+    N, H, W = shape
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    x = torch.randn(N, 3, H, W, generator=g).cuda().to(xdtype)
+    if H == 96:
+        x = x.contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(64, 3, 7, 7, generator=g) * 0.1).cuda()
+    lib = _C.lib()
+    xp = torch.empty(lib.sihl_stem_xp_bytes(N, H, W) // 2, dtype=torch.bfloat16, device="cuda")
+    wp = torch.empty(64 * 7 * 32, dtype=torch.bfloat16, device="cuda")
+    out = torch.empty(N, H // 2, W // 2, 64, dtype=torch.bfloat16, device="cuda")
+    rows = lib.sihl_stem_stats_rows(N, H)
+    stats = torch.empty(rows, 2, 64, dtype=torch.float32, device="cuda")
+    rc = lib.sihl_stem_conv_fwd(ops._p(x), ops._dt(x), *x.stride(), ops._p(w), *w.stride(), ops._p(xp), ops._p(wp), ops._p(out),
+                                ops._p(stats), N, H, W, ops._stream())
+    assert rc == 0
+    ref = F.conv2d(x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), None, 2, 3)
+    got = out.float().permute(0, 3, 1, 2)
+    scale = float(ref.abs().max())
+    torch.testing.assert_close(got, ref, rtol=1e-2, atol=1e-2 * scale)  # bf16 output rounding
+    # statistics are taken from the fp32 accumulators (before the bf16 store)
+    torch.testing.assert_close(stats[:, 0].sum(0), ref.sum((0, 2, 3)), rtol=1e-3, atol=1e-3 * ref.numel() ** 0.5 / 8 * scale)
+    torch.testing.assert_close(stats[:, 1].sum(0), (ref * ref).sum((0, 2, 3)), rtol=1e-3, atol=1e-3 * scale * scale)
+    # the packed image: the bf16 image inside a zero border
+    Wp = xp.numel() // (N * (H + 6) * 3)
+    xpv = xp.view(N, H + 6, Wp, 3)
+    assert torch.equal(xpv[:, 3:3 + H, 4:4 + W], x.to(torch.bfloat16).permute(0, 2, 3, 1))
+    assert float(xpv[:, :3].abs().max()) == 0 and float(xpv[:, 3 + H:].abs().max()) == 0
+    assert float(xpv[:, :, :4].abs().max()) == 0 and float(xpv[:, :, 4 + W:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_native_stem_as_close_to_fp32_as_aten_stem(train, monkeypatch):
+    """The whole stem (conv1 -> bn1 -> relu -> maxpool -> layer1) under bf16 autocast: the native path (StemFn:
+    sihl_stem_conv_fwd + epilogue statistics + the fused BatchNorm kernels; weight gradient by ATen over the packed image)
+    and the PyTorch-ROCm conv path of the same module (SIHL_ATEN_STEM=1), each against an fp32 run: level-1 / level-2
+    outputs, the gradients of conv1 and bn1, bn1's running statistics.  bf16 moves the first conv's weight gradient by
+    ~15 % of its norm in this setting whichever kernel computes it (tools/stem_probe.py), so the bar is relative: the native
+    path may be at most 1.3 x as far from fp32 as the ATen path (+ 1 % of the norm)."""
+    import sihl_amd
+
+    torch.manual_seed(5)
+    model = sihl_amd.ResNetBackbone("resnet18", native=True, top_level=2).cuda().train(train)
+    x = torch.rand(4, 3, 96, 128, device="cuda")
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def run(mode):
+        model.load_state_dict(state)
+        model.zero_grad(set_to_none=True)
+        if mode == "native":
+            monkeypatch.delenv("SIHL_ATEN_STEM", raising=False)
+        else:
+            monkeypatch.setenv("SIHL_ATEN_STEM", "1")
+        if mode == "fp32":
+            outs = model(x)
+        else:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                outs = model(x)
+        t = model.model
+        res = [o.float().detach() for o in outs[1:]]
+        if train:
+            gc = torch.Generator(device="cuda").manual_seed(9)  # random cotangents: well-conditioned gradients
+            sum((o.float() * torch.randn(o.shape, device="cuda", generator=gc)).mean() for o in outs[1:]).backward()
+            res += [t.conv1.weight.grad.clone(), t.bn1.weight.grad.clone(), t.bn1.bias.grad.clone(),
+                    t.bn1.running_mean.clone(), t.bn1.running_var.clone()]
+        return res
+
+    ref, native, aten = run("fp32"), run("native"), run("aten")
+    names = ["level 1", "level 2", "conv1.weight.grad", "bn1.weight.grad", "bn1.bias.grad", "running_mean", "running_var"]
+    for nm, r, a, b in zip(names, ref, native, aten):
+        ea, eb = float((a - r).norm() / r.norm()), float((b - r).norm() / r.norm())
+        assert ea <= 1.3 * eb + 1e-2, (nm, ea, eb)
