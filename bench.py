@@ -548,7 +548,7 @@ def main():
                                    "fwd + bwd + grad all-reduce + clip(0.1) + AdamW, random-init weights",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "image": f"3x{args.size}x{args.size}", "parallelism": f"dp{world}",
-                       "backbone": "resnet50 trunk on " + ("sihl HIP kernels (stem on PyTorch-ROCm)"
+                       "backbone": "resnet50 trunk on " + ("sihl HIP kernels (bf16: incl. the 7x7 stem conv, csrc/stem.hip)"
                                                             if args.backbone == "native" else "PyTorch-ROCm (MIOpen/CK)"),
                        "wgrad_stream": "off" if use_graph else args.wgrad_stream,
                        "execution": "one HIP graph replay per step" if use_graph else

@@ -154,6 +154,12 @@ int sihl_stem_stats_rows(int N, int H);
 int sihl_stem_conv_fwd(const void* x, int x_dtype, long xsn, long xsc, long xsh, long xsw, const float* w, long wso, long wsc,
                        long wsh, long wsw, void* xp, void* wp, void* out, float* stats, int N, int H, int W,
                        hipStream_t stream);
+/* Weight gradient of that conv: dw[64][3][7][7] (fp32, element strides given) from dz[N][H/2][W/2][64] (bf16, the gradient
+ * of `out`) and the packed image xp the forward wrote; ws: sihl_stem_wgrad_parts(N, H) * 64 * 7 * 32 floats (fp32 partials,
+ * summed in a fixed order: deterministic).  The image needs no gradient: there is no dgrad entry. */
+int sihl_stem_wgrad_parts(int N, int H);
+int sihl_stem_conv_wgrad(const void* xp, const void* dz, float* dw, long wso, long wsc, long wsh, long wsw, float* ws, int N,
+                         int H, int W, hipStream_t stream);
 
 /* Batch statistics of an NHWC tensor another kernel produced (the ResNet stem's MIOpen conv): per-channel (sum, sumsq)
  * partial rows [sihl_bn_stats_rows(...)][2][C] in the layout sihl_bn_finalize reads (torchvision resnet.py stem:

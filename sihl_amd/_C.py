@@ -62,6 +62,8 @@ SIGNATURES = {
     "sihl_stem_xp_bytes": (L, [I, I, I]),
     "sihl_stem_stats_rows": (I, [I, I]),
     "sihl_stem_conv_fwd": (I, [P, I, L, L, L, L, P, L, L, L, L, P, P, P, P, I, I, I, P]),
+    "sihl_stem_wgrad_parts": (I, [I, I]),
+    "sihl_stem_conv_wgrad": (I, [P, P, P, L, L, L, L, P, I, I, I, P]),
     "sihl_norm_act_bwd_ws_bytes": (L, [L, I, I]),
     "sihl_norm_act_bwd": (I, [P, P, P, L, I, P, P, P, P, P, P, I, I, I, I, P, L, P]),
     "sihl_norm_add_relu_bwd": (I, [P, P, P, P, P, P, L, I, P, P, P, P, P, P, I, I, P, L, P]),

@@ -10,7 +10,9 @@ the same fused conv block the FPN uses, and the block tail is one normalise + ad
 parity-tested against the oracle ResNet in tests/test_gpu_backbone.py.  ``native=False`` runs the trunk on
 PyTorch-ROCm (MIOpen/CK), which SURVEY §8 a2 allows ("not a hand-kernel target").  Measured on the flagship step
 (round 1, bs 32, 512^2, bf16): 689 img/s native vs 666 img/s MIOpen, and native has no ~45 s MIOpen JIT in the first
-iteration.  The 7x7 stem conv (3 input channels) stays on PyTorch-ROCm in both modes; in native training mode its
+iteration.  The stem (conv1 7x7 / stride 2 over 3 channels -> bn1 -> relu -> max-pool): in bf16 (autocast) the native mode
+runs all of it on the sihl kernels - the conv and its weight gradient on csrc/stem.hip (round 3, ops.StemFn: 150 + 115 us
+against 254 + 244 us for MIOpen's kernels and a 60 us statistics pass); in fp32 the conv stays on PyTorch-ROCm and its
 BatchNorm + ReLU and the max-pool run on the sihl kernels (ops.bn_act_train, ops.maxpool3x3s2).  CPU tensors (BASELINE
 config 1, "stock PyTorch plumbing") always run through plain torch ops with the same parameters.
 """
@@ -158,7 +160,7 @@ class _Trunk(nn.Module):
         if native and self.bn1.training and torch.is_grad_enabled() and z.is_cuda and z.dtype in (torch.bfloat16, torch.float32) \
                 and z.shape[1] % vec == 0 and self.bn1.momentum is not None and self.bn1.track_running_stats \
                 and self.bn1.weight.requires_grad and not os.environ.get("SIHL_ATEN_STEM_BN"):  # env: A/B switch
-            # the stem's conv stays MIOpen's (7x7 over 3 channels); its BatchNorm + ReLU, forward and backward, run on
+            # fp32 (or an unsupported stem): the conv stays MIOpen's; its BatchNorm + ReLU, forward and backward, run on
             # the sihl kernels: statistics + finalize + one normalise pass instead of MIOpen's three BN kernels and an
             # ATen ReLU, and one reduce + one apply pass backward instead of threshold_backward + two BN kernels
             taps = [ops.nchw_view(ops.bn_act_train(ops.nhwc(z), self.bn1, "relu"))]

@@ -42,7 +42,7 @@ __host__ __device__ inline int stem_wp(int W) {      // padded row length in pix
 
 // x: [N][3][H][W] with element strides (sn, sc, sh, sw), fp32 or bf16 -> xp bf16 [N][H + 6][Wp][3], zero border.
 // A thread writes 4 pixels = 24 bytes (three 8-byte stores).
-template <typename TI, bool VEC4 = false>
+template <typename TI, int VEC4 = 0>  // VEC4: 1 = fp32 planes (NCHW), 2 = fp32 channels-last (NHWC): 16-byte loads
 __global__ void stem_pack_image_kernel(const TI* __restrict__ x, long sn, long sc, long sh, long sw, uint16_t* __restrict__ xp,
                                        int N, int H, int W, int Wp) {
   const int Hp = H + 2 * STOP, q = Wp / 4;
@@ -54,7 +54,20 @@ __global__ void stem_pack_image_kernel(const TI* __restrict__ x, long sn, long s
     const long n = r / Hp;
     const int iy = py - STOP;
     uint16_t v[12];
-    if (VEC4) {  // fp32 planes with unit pixel stride, 16-byte aligned rows: one float4 per channel (px0 - 4 is a multiple of 4)
+    if (VEC4 == 2) {  // fp32 NHWC: the 4 pixels are 12 consecutive floats
+      const int ix0 = px0 - SLEFT;
+      float f[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) f[k] = 0.f;
+      if (iy >= 0 && iy < H && ix0 >= 0 && ix0 + 3 < W) {
+        const float4* src = (const float4*)((const float*)x + n * sn + (long)iy * sh + (long)ix0 * 3);
+        const float4 a = src[0], b = src[1], c = src[2];
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+        f[8] = c.x; f[9] = c.y; f[10] = c.z; f[11] = c.w;
+      }
+#pragma unroll
+      for (int k = 0; k < 12; ++k) v[k] = f32_to_bf16(f[k]);
+    } else if (VEC4 == 1) {  // fp32 planes with unit pixel stride, 16-byte aligned rows: one float4 per channel (px0 - 4 is a multiple of 4)
       const int ix0 = px0 - SLEFT;
       const bool ok = iy >= 0 && iy < H && ix0 >= 0 && ix0 + 3 < W;
 #pragma unroll
@@ -198,6 +211,139 @@ __global__ __launch_bounds__(256, 2) void stem_conv_fwd_kernel(const uint16_t* _
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient: dwp[co][ky][j] = sum over output pixels of dz[pixel][co] * xp[n][2 oy + ky][6 ox + j] - the contraction runs
+// over PIXELS, the slow axis of both operands, so 64-pixel tiles are staged [pixel][channel] in LDS (dz: 64 x 64; the
+// image: per kernel row the 64 pixels' 32-element segments, 64 B rows) and the MFMA operands are read TRANSPOSED
+// (ds_read_b64_tr_b16, as conv_wgrad.hip).  The 4 x 14 accumulator tiles (16 channels x 16 j per (kernel row, j half)) are
+// dealt 2 x 7 to each of the four waves; a workgroup walks `rows_per_wg` output rows and writes ONE fp32 partial
+// [64][224]; stem_wgrad_reduce_kernel sums the partials in order and scatters them to the [64][3][7][7] gradient.
+constexpr int GK = 64;                    // pixels per stage
+constexpr int DZROW = SCO * 2 + 16;       // bytes per dz row in LDS (padded)
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+__global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const uint16_t* __restrict__ xp, const uint16_t* __restrict__ dz,
+                                                          float* __restrict__ part, int N, int H, int W, int Wp, int Ho, int Wo,
+                                                          int rows_per_wg) {
+  __shared__ __attribute__((aligned(16))) char dzl[GK * DZROW];             // 9 KiB
+  __shared__ __attribute__((aligned(16))) uint16_t xl[SKY][GK][SSEG];       // 28 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+  const int Hp = H + 2 * STOP;
+  // wave (wa, wb): output channels 32 wa .. 32 wa + 31 (two 16-row tiles) x seven of the 14 (kernel row, j tile) column
+  // tiles (tile id 7 wb + k = 2 ky + jt): 18 transposed reads per 14 MFMAs (one wave per channel tile took 30)
+  const int wa = wave & 1, wb = wave >> 1;
+  f32x4_t acc[2][SKY];
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+    for (int k = 0; k < SKY; ++k) acc[ci][k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const long nrows = (long)N * Ho;
+  const long r_begin = (long)blockIdx.x * rows_per_wg, r_end = r_begin + rows_per_wg < nrows ? r_begin + rows_per_wg : nrows;
+  const int spr = (Wo + GK - 1) / GK;                       // stages per output row
+  const int nstages = (int)(r_end - r_begin) * spr;
+  // stage s = (row r_begin + s / spr, pixels (s % spr) * 64 ...): its global loads are issued one stage ahead, so they
+  // fly under the previous stage's multiplies (a stage is ~40 MFMA-cycles of work per byte loaded: latency, not bandwidth)
+  uint4 rd[2], rx[SKY];
+  auto load_stage = [&](int st) {
+    const long r = r_begin + st / spr;
+    const int ox0 = (st % spr) * GK;
+    const int n = (int)(r / Ho), oy = (int)(r % Ho);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int idx = tid + 256 * k, px = idx >> 3, c = idx & 7;
+      rd[k] = (ox0 + px < Wo) ? *(const uint4*)(dz + ((r * Wo + ox0 + px) * SCO + c * 8)) : make_uint4(0, 0, 0, 0);
+    }
+    const int px = tid >> 2, c = tid & 3;
+    const uint16_t* xs = xp + (((long)n * Hp + 2 * oy) * Wp) * 3 + 6 * (ox0 + px) + 8 * c;
+#pragma unroll
+    for (int ky = 0; ky < SKY; ++ky) rx[ky] = ld_seg(xs + (long)ky * Wp * 3);
+  };
+  if (nstages > 0) load_stage(0);
+  for (int st = 0; st < nstages; ++st) {
+    {
+      __syncthreads();  // the previous stage has been multiplied
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int idx = tid + 256 * k, px = idx >> 3, c = idx & 7;
+        *(uint4*)(dzl + px * DZROW + c * 16) = rd[k];
+      }
+      {
+        const int px = tid >> 2, c = tid & 3;
+#pragma unroll
+        // 16-byte chunk c of pixel px sits at position c ^ 2 in rows 8-15, 24-31, ...: the two lane groups of a half wave
+        // (pixel rows 8 apart) then read different bank halves
+        for (int ky = 0; ky < SKY; ++ky) *(uint4*)(&xl[ky][px][(c ^ (((px >> 3) & 1) << 1)) * 8]) = rx[ky];
+      }
+      __syncthreads();
+      if (st + 1 < nstages) load_stage(st + 1);
+      // ---- multiply: two 32-pixel k-steps
+#pragma unroll
+      for (int ks = 0; ks < GK / 32; ++ks) {
+        const int row = ks * 32 + 8 * g + q;  // (+ 4 for the second transposed read)
+        bf16x8_t a[2];
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci) {
+          const char* pa = dzl + row * DZROW + (16 * (2 * wa + ci) + 4 * pp) * 2;
+          const s16x4_t alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)pa);
+          const s16x4_t ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pa + 4 * DZROW));
+          a[ci] = __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int k = 0; k < SKY; ++k) {
+          const int t = 7 * wb + k, ky = t >> 1, jt = t & 1;
+          const uint16_t* pb = &xl[ky][row][16 * (jt ^ (g & 1)) + 4 * pp];  // ((row >> 3) & 1) == (g & 1)
+          const s16x4_t blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)pb);
+          const s16x4_t bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pb + 4 * SSEG));
+          const bf16x8_t b = __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+          for (int ci = 0; ci < 2; ++ci) acc[ci][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ci], b, acc[ci][k], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D[co = 32 wa + 16 ci + 4 g + r][column tile 7 wb + k][j = lane % 16]
+  float* dst = part + (long)blockIdx.x * SCO * SKY * SSEG;
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+    for (int k = 0; k < SKY; ++k) {
+      const int t = 7 * wb + k, ky = t >> 1, jt = t & 1;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        dst[((32 * wa + 16 * ci + 4 * g + rr) * SKY + ky) * SSEG + 16 * jt + i16] = acc[ci][k][rr];
+    }
+}
+
+// dw[co][c][ky][kx] (element strides given) = sum_k part[k][co][ky][3 (kx + 1) + c].  256 threads = 32 outputs x 8 slices of
+// the partials (k = kk, kk + 8, ...), folded through LDS in slice order: deterministic.
+__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ part, int nparts, float* __restrict__ dw, long so, long sc,
+                                         long sh, long sw) {
+  __shared__ float red[8][32];
+  const int ii = threadIdx.x & 31, kk = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + ii;  // SCO * SKY * SSEG is a multiple of 32
+  float a0 = 0.f, a1 = 0.f;
+  int k = kk;
+  for (; k + 8 < nparts; k += 16) {
+    a0 += part[(long)k * SCO * SKY * SSEG + i];
+    a1 += part[(long)(k + 8) * SCO * SKY * SSEG + i];
+  }
+  if (k < nparts) a0 += part[(long)k * SCO * SKY * SSEG + i];
+  red[kk][ii] = a0 + a1;
+  __syncthreads();
+  if (kk == 0) {
+    const int j = i % SSEG, ky = (i / SSEG) % SKY, co = i / (SSEG * SKY);
+    if (j >= 3 && j < 24) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += red[q][ii];
+      dw[co * so + (j % 3) * sc + ky * sh + (j / 3 - 1) * sw] = t;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -219,8 +365,13 @@ int sihl_stem_conv_fwd(const void* x, int x_dtype, long xsn, long xsc, long xsh,
   if (gp > 65535) gp = 65535;
   const bool vec4 = x_dtype == SIHL_F32 && xsw == 1 && (W % 4) == 0 && (xsh % 4) == 0 && (xsc % 4) == 0 && (xsn % 4) == 0 &&
                     ((uintptr_t)x % 16) == 0;
+  const bool nhwc4 = x_dtype == SIHL_F32 && xsc == 1 && xsw == 3 && (W % 4) == 0 && (xsh % 4) == 0 && (xsn % 4) == 0 &&
+                     ((uintptr_t)x % 16) == 0;
   if (vec4)
-    hipLaunchKernelGGL((stem_pack_image_kernel<float, true>), dim3((unsigned)gp), dim3(256), 0, stream, (const float*)x, xsn, xsc, xsh,
+    hipLaunchKernelGGL((stem_pack_image_kernel<float, 1>), dim3((unsigned)gp), dim3(256), 0, stream, (const float*)x, xsn, xsc, xsh,
+                       xsw, (uint16_t*)xp, N, H, W, Wp);
+  else if (nhwc4)
+    hipLaunchKernelGGL((stem_pack_image_kernel<float, 2>), dim3((unsigned)gp), dim3(256), 0, stream, (const float*)x, xsn, xsc, xsh,
                        xsw, (uint16_t*)xp, N, H, W, Wp);
   else if (x_dtype == SIHL_F32)
     hipLaunchKernelGGL(stem_pack_image_kernel<float>, dim3((unsigned)gp), dim3(256), 0, stream, (const float*)x, xsn, xsc, xsh, xsw,
@@ -234,6 +385,31 @@ int sihl_stem_conv_fwd(const void* x, int x_dtype, long xsn, long xsc, long xsh,
   const int grid = N * ((Ho + SROWS - 1) / SROWS);
   hipLaunchKernelGGL(stem_conv_fwd_kernel, dim3(grid), dim3(256), 0, stream, (const uint16_t*)xp, (const uint16_t*)wp,
                      (uint16_t*)out, stats, N, H, W, Wp, Ho, Wo);
+  SIHL_CHECK_LAUNCH();
+  return SIHL_OK;
+}
+
+// workgroups (= fp32 partials of 64 * 7 * 32 floats each) of the weight gradient
+int sihl_stem_wgrad_parts(int N, int H) {
+  const long nrows = (long)N * (H / 2);
+  long rpw = (nrows + 511) / 512;  // (1 024 workgroups: the kernel 115 -> 103 us, the reduction 12 -> 22: no gain)
+  if (rpw < 1) rpw = 1;
+  return (int)((nrows + rpw - 1) / rpw);
+}
+
+// dw[64][3][7][7] (fp32, element strides given) = weight gradient of the stem conv for dz[N][H/2][W/2][64] (bf16), from the
+// packed image xp that sihl_stem_conv_fwd wrote.  ws: sihl_stem_wgrad_parts(N, H) * 64 * 7 * 32 floats.
+int sihl_stem_conv_wgrad(const void* xp, const void* dz, float* dw, long wso, long wsc, long wsh, long wsw, float* ws, int N,
+                         int H, int W, hipStream_t stream) {
+  if (!xp || !dz || !dw || !ws || N <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1)) return SIHL_EARG;
+  const int Wp = stem_wp(W), Ho = H / 2, Wo = W / 2;
+  const long nrows = (long)N * Ho;
+  const int parts = sihl_stem_wgrad_parts(N, H);
+  const int rpw = (int)((nrows + parts - 1) / parts);
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(parts), dim3(256), 0, stream, (const uint16_t*)xp, (const uint16_t*)dz, ws, N, H, W, Wp,
+                     Ho, Wo, rpw);
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(SCO * SKY * SSEG / 32), dim3(256), 0, stream, (const float*)ws, parts,
+                     dw, wso, wsc, wsh, wsw);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
 }

@@ -61,6 +61,7 @@ def _sized(name: str, *args):
     return v
 
 _SPLIT_TAIL_BWD = bool(os.environ.get("SIHL_SPLIT_TAIL_BWD"))
+_ATEN_STEM_WGRAD = bool(os.environ.get("SIHL_ATEN_STEM_WGRAD"))
 TAIL_MASK_BITS = os.environ.get("SIHL_TAIL_MASK_BITS", "1") != "0"  # A/B / test switch: 0 = the tail's backward re-reads y
 
 # ---- BatchNorm step counters: one multi-tensor add per training step instead of one tiny kernel per layer
@@ -561,7 +562,7 @@ class StemFn(torch.autograd.Function):
     the 7x7 / stride 2 conv over 3 channels on ``sihl_stem_conv_fwd`` (csrc/stem.hip: the image packed once into a padded
     NHWC bf16 copy, kernel rows as 32-element K segments), its batch statistics from the conv's own epilogue, then the
     finalize / normalise / backward kernels of the fused conv block.  NCHW image in, NHWC activation out.  The weight
-    gradient runs on ATen's convolution_backward (MIOpen) over the packed image."""
+    gradient is ``sihl_stem_conv_wgrad`` over the same packed image (SIHL_ATEN_STEM_WGRAD=1: ATen's, for the A/B)."""
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, eps, momentum, act, training):
@@ -592,7 +593,12 @@ class StemFn(torch.autograd.Function):
         N, H, W = ctx.shape
         dz, dgamma, dbeta = norm_act_bwd(s, dy.contiguous(), mean, rstd, gamma, beta, 1, ctx.act, ctx.training)
         dw = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not _ATEN_STEM_WGRAD:
+            dw = torch.empty((64, 3, 7, 7), dtype=torch.float32, device=dz.device)
+            ws = workspace(_sized("sihl_stem_wgrad_parts", N, H) * 64 * 7 * 32 * 4, dz.device)
+            rc = _C.lib().sihl_stem_conv_wgrad(_p(xp), _p(dz), _p(dw), *dw.stride(), _p(ws), N, H, W, _stream())
+            check(rc, "sihl_stem_conv_wgrad")
+        elif ctx.needs_input_grad[1]:  # A/B switch: MIOpen's weight gradient over the packed image
             Wp = xp.numel() // (N * (H + 6) * 3)
             x_img = xp.view(N, H + 6, Wp, 3)[:, 3:3 + H, 4:4 + W, :].permute(0, 3, 1, 2)  # the image, bf16, NCHW view
             dw = torch.ops.aten.convolution_backward(nchw_view(dz), x_img, w.to(torch.bfloat16), None, [2, 2], [3, 3], [1, 1],

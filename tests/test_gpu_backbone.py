@@ -129,6 +129,40 @@ def test_stem_conv_kernel_matches_torch(shape, xdtype):
     assert float(xpv[:, :, :4].abs().max()) == 0 and float(xpv[:, :, 4 + W:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 64), (1, 130, 70), (3, 96, 256), (40, 16, 32)])
+def test_stem_wgrad_kernel_matches_torch(shape):
+    """sihl_stem_conv_wgrad (gradient of conv1's [64][3][7][7] weights from the packed image and the bf16 output gradient,
+    transposed LDS reads, fp32 partials summed in a fixed order) against torch's fp32 conv2d weight gradient of the same
+    bf16-rounded tensors; run twice: bit-identical.  Widths that are not multiples of the 64-pixel stage, more row groups
+    than workgroups, a non-contiguous gradient tensor (strides)."""
+    import torch.nn.functional as F
+    from sihl_amd import _C, ops
+
+    N, H, W = shape
+    g = torch.Generator().manual_seed(H * 77 + W)
+    x = torch.randn(N, 3, H, W, generator=g).cuda()
+    w = (torch.randn(64, 3, 7, 7, generator=g) * 0.1).cuda()
+    dz = torch.randn(N, H // 2, W // 2, 64, generator=g).cuda().to(torch.bfloat16)
+    lib = _C.lib()
+    xp = torch.empty(lib.sihl_stem_xp_bytes(N, H, W) // 2, dtype=torch.bfloat16, device="cuda")
+    wp = torch.empty(64 * 7 * 32, dtype=torch.bfloat16, device="cuda")
+    out = torch.empty(N, H // 2, W // 2, 64, dtype=torch.bfloat16, device="cuda")
+    assert lib.sihl_stem_conv_fwd(ops._p(x), ops._dt(x), *x.stride(), ops._p(w), *w.stride(), ops._p(xp), ops._p(wp), ops._p(out),
+                                  None, N, H, W, ops._stream()) == 0
+    ws = torch.empty(lib.sihl_stem_wgrad_parts(N, H) * 64 * 7 * 32, dtype=torch.float32, device="cuda")
+    res = []
+    for layout in ("oihw", "ohwi"):
+        dw = torch.full((64, 3, 7, 7), float("nan"), device="cuda")
+        if layout == "ohwi":
+            dw = dw.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)  # channels-last strides
+        assert lib.sihl_stem_conv_wgrad(ops._p(xp), ops._p(dz), ops._p(dw), *dw.stride(), ops._p(ws), N, H, W, ops._stream()) == 0
+        res.append(dw)
+    assert torch.equal(res[0], res[1].contiguous())
+    xr = x.to(torch.bfloat16).float()
+    ref = torch.nn.grad.conv2d_weight(xr, (64, 3, 7, 7), dz.float().permute(0, 3, 1, 2), stride=2, padding=3)
+    torch.testing.assert_close(res[0], ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("train", [True, False])
 def test_native_stem_as_close_to_fp32_as_aten_stem(train, monkeypatch):
     """The whole stem (conv1 -> bn1 -> relu -> maxpool -> layer1) under bf16 autocast: the native path (StemFn:
