@@ -11,7 +11,7 @@ parity-tested against the oracle ResNet in tests/test_gpu_backbone.py.  ``native
 PyTorch-ROCm (MIOpen/CK), which SURVEY §8 a2 allows ("not a hand-kernel target").  Measured on the flagship step
 (round 1, bs 32, 512^2, bf16): 689 img/s native vs 666 img/s MIOpen, and native has no ~45 s MIOpen JIT in the first
 iteration.  The stem (conv1 7x7 / stride 2 over 3 channels -> bn1 -> relu -> max-pool): in bf16 (autocast) the native mode
-runs all of it on the sihl kernels - the conv and its weight gradient on csrc/stem.hip (round 3, ops.StemFn: 150 + 115 us
+runs all of it on the sihl kernels - the conv and its weight gradient on csrc/stem.hip (round 3, ops.StemFn: 130 + 115 us
 against 254 + 244 us for MIOpen's kernels and a 60 us statistics pass); in fp32 the conv stays on PyTorch-ROCm and its
 BatchNorm + ReLU and the max-pool run on the sihl kernels (ops.bn_act_train, ops.maxpool3x3s2).  CPU tensors (BASELINE
 config 1, "stock PyTorch plumbing") always run through plain torch ops with the same parameters.
