@@ -212,21 +212,41 @@ class ObjectDetection(nn.Module):
     @staticmethod
     def _pad_targets(boxes: List[Tensor], classes: List[Tensor], device) -> Tuple[Tensor, Tensor, Tensor]:
         """Per-image target lists -> (B, G, 4) boxes, (B, G) classes, (B, G) validity, G = batch maximum.
-        Padding is marked with NaN boxes so validity is derived on the device (no count upload); padded slots then
-        get a degenerate-free placeholder box that keeps the CIoU arithmetic finite."""
+        Padded slots get a degenerate-free placeholder box that keeps the CIoU arithmetic finite."""
         B = len(boxes)
         G = max([int(b.shape[0]) for b in boxes], default=0)  # host-side shapes: no device sync
         if G == 0:
             return (torch.zeros((B, 0, 4), device=device), torch.zeros((B, 0), device=device, dtype=torch.int64),
                     torch.zeros((B, 0), device=device, dtype=torch.bool))
-        pad = torch.nn.utils.rnn.pad_sequence
-        gt = pad([b.to(device=device, dtype=torch.float32).reshape(-1, 4) for b in boxes], batch_first=True,
-                 padding_value=float("nan"))
-        cls = pad([c.to(device=device, dtype=torch.int64).reshape(-1) for c in classes], batch_first=True)
-        col_ok = ~gt[..., 0].isnan()
-        placeholder = torch.zeros_like(gt)
-        placeholder[..., 2:] = 1.0
-        return torch.where(col_ok[..., None], gt, placeholder), cls, col_ok
+        # ONE concatenation per tensor instead of pad_sequence's device copy PER IMAGE (64 tiny copies per step at batch 32):
+        # image i contributes its k_i rows followed by G - k_i rows of a constant (placeholder box / class 0 / False); the
+        # row counts are host-side shapes, so nothing is uploaded and nothing syncs
+        ph_box, ph_cls, ph_true, ph_false = ObjectDetection._padding_constants(device, G)
+        parts_b, parts_c, parts_ok = [], [], []
+        for b, c in zip(boxes, classes):
+            k = int(b.shape[0])
+            parts_b += [b.to(device=device, dtype=torch.float32).reshape(-1, 4), ph_box[:G - k]]
+            parts_c += [c.to(device=device, dtype=torch.int64).reshape(-1), ph_cls[:G - k]]
+            parts_ok += [ph_true[:k], ph_false[:G - k]]
+        return torch.cat(parts_b).view(B, G, 4), torch.cat(parts_c).view(B, G), torch.cat(parts_ok).view(B, G)
+
+    _PAD_CONST = {}
+
+    @staticmethod
+    def _padding_constants(device, G: int):
+        """(G, 4) placeholder boxes [0, 0, 1, 1] (keep the CIoU arithmetic finite in padded slots), G zeros (class), G
+        True / G False - made once per device and grown on demand (device-side fills: no upload)."""
+        key = str(device)
+        c = ObjectDetection._PAD_CONST.get(key)
+        if c is None or c[0].shape[0] < G or torch.cuda.is_current_stream_capturing():
+            n = max(G, 64)
+            box = torch.zeros((n, 4), device=device)
+            box[:, 2:] = 1.0
+            c = (box, torch.zeros(n, device=device, dtype=torch.int64), torch.ones(n, device=device, dtype=torch.bool),
+                 torch.zeros(n, device=device, dtype=torch.bool))
+            if not torch.cuda.is_current_stream_capturing():  # constants made inside a capture live in the graph's pool
+                ObjectDetection._PAD_CONST[key] = c
+        return c
 
     @staticmethod
     def _match_padded(anchors: Tensor, gt: Tensor, col_ok: Tensor, topk: int) -> Tuple[Tensor, Tensor, Tensor]:

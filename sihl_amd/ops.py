@@ -522,6 +522,11 @@ def colsum(x: Tensor, off_chain: bool = False) -> Tensor:
             rc = lib.sihl_colsum(_p(x), rows, C, _p(out), _dt(x), _p(ws), ws.numel(), _stream())
         side.holds.append((x, x, out))
         side.dirty = True
+        check(rc, "sihl_colsum")
+        # handed on as a VIEW (a tensor object of its own): AccumulateGrad takes a gradient as it is only when nothing else
+        # references that tensor object - `holds` does - and otherwise clones it, on the main stream, which may run before
+        # the side stream has written it (same contract as the weight gradients, which leave as permuted views)
+        return out.view(C)
     else:
         ws = workspace(_sized("sihl_colsum_ws_bytes", rows, C), x.device)
         rc = lib.sihl_colsum(_p(x), rows, C, _p(out), _dt(x), _p(ws), ws.numel(), _stream())
