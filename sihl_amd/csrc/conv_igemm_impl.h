@@ -669,7 +669,7 @@ __global__ __launch_bounds__(WM * WN * 64, (conv_min_waves<BM, BN, WM * WN>())) 
     //   0: NA/NBL slots spread over the k-steps   1: everything before the first k-step
     //   2: staggered - waves of the first half issue before k-step 0, the others after k-step 1
     //   3: front-loaded - slots spread over the first half of the k-steps
-    const int sched = (SIHL_DBG(p) & 16) ? ((SIHL_DBG(p) >> 2) & 3) : ((BM >= 256 && NBUF == 2) ? 3 : 1);
+    const int sched = (SIHL_DBG(p) & 16) ? ((SIHL_DBG(p) >> 2) & 3) : ((BM >= 256 && NBUF == 2 && WM * WN == 8) ? 3 : 1);
     const bool early = sched == 1 || (sched == 2 && wave < WM * WN / 2);
     constexpr int NKSH = NKS / 2 > 0 ? NKS / 2 : 1;
     if (!(SIHL_DBG(p) & 2)) {
