@@ -48,6 +48,7 @@ def _stream():
 
 
 _WS = {}
+_WS_RETIRED = []
 _SIZES = {}
 
 
@@ -93,11 +94,17 @@ class deferred_bn_counters:
         return False
 
 
-def workspace(nbytes: int, device) -> Tensor:
-    """Grow-only scratch buffer per device and stream (kernels are stream-ordered, so one buffer is shared)."""
-    key = (device.index, _stream())
+def workspace(nbytes: int, device, stream=None) -> Tensor:
+    """Grow-only scratch buffer per device and stream (kernels are stream-ordered, so one buffer is shared).  stream: raw
+    handle of the stream the kernel will be launched on when that is not torch's current stream (side-stream launches by
+    handle: they must NOT share the current stream's buffer)."""
+    key = (device.index, _stream() if stream is None else stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None and stream is not None:
+            # outgrown while kernels of ANOTHER stream may still use it: the block belongs to the current stream's pool, so
+            # it is kept (a handful of buffers during the first steps) rather than handed back under a running kernel
+            _WS_RETIRED.append(buf)
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _WS[key] = buf
     return buf
@@ -111,10 +118,12 @@ def workspace(nbytes: int, device) -> Tensor:
 # side stream reads, so they are held alive until the join (the caching allocator would otherwise hand their blocks
 # to later main-stream kernels while the wgrad is still queued).
 class _Side:
-    __slots__ = ("stream", "holds", "mode", "dirty", "seen")
+    __slots__ = ("stream", "handle", "holds", "mode", "dirty", "seen")
 
     def __init__(self, stream, mode):
         self.stream, self.holds, self.mode, self.dirty, self.seen = stream, [], mode, False, set()
+        self.handle = stream.cuda_stream  # kernels are launched on it BY HANDLE: entering torch.cuda.stream(...) per launch
+        #                                   cost ~10 us of host time x 140 launches per step
 
 
 _SIDE: Optional[_Side] = None
@@ -377,10 +386,9 @@ def conv2d_wgrad_raw(x: Tensor, dout: Tensor, KH: int, KW: int, stride: int, pad
     if side is not None and dout.numel() // Cout <= WGRAD_SIDE_MAX_PIXELS[side.mode]:
         nbytes = _sized("sihl_conv2d_wgrad_ws_bytes", N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x), SIDE_WGRAD_TARGET)
         side.stream.wait_stream(torch.cuda.current_stream())  # x and dout are complete on the main stream
-        with torch.cuda.stream(side.stream):
-            ws = workspace(nbytes, x.device)  # the side stream's own scratch buffer (keyed by stream)
-            rc = lib.sihl_conv2d_wgrad(_p(x), _p(dout), _p(dw), N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x),
-                                       0, SIDE_WGRAD_TARGET, _p(ws), ws.numel(), _stream())
+        ws = workspace(nbytes, x.device, side.handle)  # the side stream's own scratch buffer (keyed by stream)
+        rc = lib.sihl_conv2d_wgrad(_p(x), _p(dout), _p(dw), N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x),
+                                   0, SIDE_WGRAD_TARGET, _p(ws), ws.numel(), side.handle)
         side.holds.append((x, dout, dw))
         side.dirty = True
     else:
@@ -517,9 +525,8 @@ def colsum(x: Tensor, off_chain: bool = False) -> Tensor:
     side = _SIDE if off_chain else None
     if side is not None and rows <= WGRAD_SIDE_MAX_PIXELS[side.mode]:
         side.stream.wait_stream(torch.cuda.current_stream())  # x is complete on the main stream
-        with torch.cuda.stream(side.stream):
-            ws = workspace(_sized("sihl_colsum_ws_bytes", rows, C), x.device)
-            rc = lib.sihl_colsum(_p(x), rows, C, _p(out), _dt(x), _p(ws), ws.numel(), _stream())
+        ws = workspace(_sized("sihl_colsum_ws_bytes", rows, C), x.device, side.handle)
+        rc = lib.sihl_colsum(_p(x), rows, C, _p(out), _dt(x), _p(ws), ws.numel(), side.handle)
         side.holds.append((x, x, out))
         side.dirty = True
         check(rc, "sihl_colsum")
