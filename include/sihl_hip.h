@@ -191,7 +191,10 @@ int sihl_norm_add_relu_bwd(const void* s, const void* dy, const void* y, const v
  * blur_fuse: out = w0 * blurpool(a) + w1 * b + w2 * c with blurpool = reflect-pad 1, [1,2,1]x[1,2,1]/16, stride 2
  *            (layers/pooling.py:7-26).  b == c == NULL: plain BlurPool2d.
  * fuse_sum : stand-alone FastNormalizedFusion of n = 2 or 3 tensors.
- * *_bwd    : input gradients (NULL = not needed) and dw_raw (softmax Jacobian applied); gacc = 2 / 3 floats. */
+ * *_bwd    : input gradients (NULL = not needed) and dw_raw (softmax Jacobian applied); gacc = SIHL_FUSION_GACC_FLOATS
+ *            floats of scratch (one partial row per workgroup of the reducing kernel, summed in a fixed order: the
+ *            fusion-weight gradients are bit-reproducible; need not be initialised). */
+#define SIHL_FUSION_GACC_FLOATS (4 * 4096)
 int sihl_fuse_up2(const void* a, const void* b, const float* wraw, void* out, int N, int H, int W, int C, int dtype,
                   hipStream_t stream);
 int sihl_fuse_up2_bwd(const void* dout, const void* a, const void* b, const float* wraw, void* da, void* db,

@@ -45,7 +45,8 @@ __device__ __forceinline__ void softmax_w(const float* raw, int n, float (&w)[3]
   for (int i = 0; i < n; ++i) w[i] /= s;
 }
 
-// block-wide sum of up to 3 values -> atomicAdd into acc[0..n)
+// block-wide sum of up to 3 values -> this workgroup's partial row acc[blockIdx.x][0..n) (row stride 4; no atomics: the
+// rows are summed in a fixed order by fusion_wgrad_kernel, so the fusion-weight gradients are bit-reproducible)
 __device__ __forceinline__ void block_accumulate(float (&v)[3], int n, float* acc) {
   __shared__ float red[3][TPB / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -57,7 +58,7 @@ __device__ __forceinline__ void block_accumulate(float (&v)[3], int n, float* ac
   if (threadIdx.x < n) {
     float s = 0.f;
     for (int w = 0; w < TPB / 64; ++w) s += red[threadIdx.x][w];
-    atomicAdd(acc + threadIdx.x, s);
+    acc[(long)blockIdx.x * 4 + threadIdx.x] = s;
   }
 }
 
@@ -751,13 +752,25 @@ __global__ void fuse_sum_bwd_kernel(const T* __restrict__ dout, const T* __restr
   if (gacc) block_accumulate(g, n, gacc);
 }
 
-// d raw_j = w_j * (g_j - sum_i w_i g_i)  (softmax Jacobian), accumulated into dw_raw
-__global__ void fusion_wgrad_kernel(const float* wraw, const float* g, float* dw_raw, int n) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    float w[3];
+// g = sum of the producing kernel's per-workgroup partial rows part[nblocks][4] (fixed order: strided per thread, then a
+// tree through LDS); d raw_j = w_j * (g_j - sum_i w_i g_i)  (softmax Jacobian) -> dw_raw
+__global__ void fusion_wgrad_kernel(const float* wraw, const float* __restrict__ part, int nblocks, float* dw_raw, int n) {
+  __shared__ float red[3][256];
+  float a[3] = {0.f, 0.f, 0.f};
+  for (int b = threadIdx.x; b < nblocks; b += 256)
+    for (int i = 0; i < n; ++i) a[i] += part[(long)b * 4 + i];
+  for (int i = 0; i < 3; ++i) red[i][threadIdx.x] = a[i];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+      for (int i = 0; i < n; ++i) red[i][threadIdx.x] += red[i][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float w[3], g[3];
     softmax_w(wraw, n, w);
     float dot = 0.f;
-    for (int i = 0; i < n; ++i) dot += w[i] * g[i];
+    for (int i = 0; i < n; ++i) { g[i] = red[i][0]; dot += w[i] * g[i]; }
     for (int j = 0; j < n; ++j) dw_raw[j] = w[j] * (g[j] - dot);
   }
 }
@@ -1450,23 +1463,25 @@ int sihl_fuse_up2(const void* a, const void* b, const float* wraw, void* out, in
   return SIHL_OK;
 }
 
-// gacc: 2 floats, zeroed by this call; da/db may be null when not needed; dw_raw (2 floats) written if non-null
+// gacc: SIHL_FUSION_GACC_FLOATS floats of scratch (per-workgroup partial sums); da/db may be null when not needed; dw_raw
+// (2 floats) written if non-null
 int sihl_fuse_up2_bwd(const void* dout, const void* a, const void* b, const float* wraw, void* da, void* db,
                       float* dw_raw, float* gacc, int N, int H, int W, int C, int dtype, hipStream_t stream) {
   if (!dout || N <= 0 || (H & 1) || (W & 1) || (dw_raw && !gacc)) return SIHL_EARG;
   if ((db || dw_raw) && (!a || !b || !wraw)) return SIHL_EARG;  // b == null: plain upsample, only da
-  if (dw_raw) { hipError_t e = hipMemsetAsync(gacc, 0, 2 * sizeof(float), stream); if (e) return (int)e; }
+  int nblk = 0;
   DISPATCH_DTYPE(dtype, {
     constexpr int V = 16 / sizeof(T);
     if (C % V) return SIHL_EARG;
+    nblk = grid_for((long)N * H * W * (C / V));
     if (db || dw_raw)
-      hipLaunchKernelGGL(fuse_up2_bwd_hi_kernel<T>, dim3(grid_for((long)N * H * W * (C / V))), dim3(TPB), 0, stream,
+      hipLaunchKernelGGL(fuse_up2_bwd_hi_kernel<T>, dim3(nblk), dim3(TPB), 0, stream,
                          (const T*)dout, (const T*)a, (const T*)b, wraw, (T*)db, dw_raw ? gacc : nullptr, N, H, W, C);
     if (da)
       hipLaunchKernelGGL(up2_adjoint_kernel<T>, dim3(grid_for((long)N * (H / 2) * (W / 2) * (C / V))), dim3(TPB), 0,
                          stream, (const T*)dout, b ? wraw : nullptr, (T*)da, N, H, W, C);
   });
-  if (dw_raw) hipLaunchKernelGGL(fusion_wgrad_kernel, dim3(1), dim3(64), 0, stream, wraw, gacc, dw_raw, 2);
+  if (dw_raw) hipLaunchKernelGGL(fusion_wgrad_kernel, dim3(1), dim3(256), 0, stream, wraw, gacc, nblk, dw_raw, 2);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
 }
@@ -1593,15 +1608,16 @@ int sihl_fuse_sum_bwd(const void* dout, const void* x0, const void* x1, const vo
                       hipStream_t stream) {
   if (!dout || !wraw || numel <= 0 || n < 2 || n > 3 || (dw_raw && (!gacc || !x0 || !x1 || (n == 3 && !x2))))
     return SIHL_EARG;
-  if (dw_raw) { hipError_t e = hipMemsetAsync(gacc, 0, 3 * sizeof(float), stream); if (e) return (int)e; }
+  int nblk = 0;
   DISPATCH_DTYPE(dtype, {
     constexpr int V = 16 / sizeof(T);
     if (numel % V) return SIHL_EARG;
-    hipLaunchKernelGGL(fuse_sum_bwd_kernel<T>, dim3(grid_for(numel / V)), dim3(TPB), 0, stream, (const T*)dout,
+    nblk = grid_for(numel / V);
+    hipLaunchKernelGGL(fuse_sum_bwd_kernel<T>, dim3(nblk), dim3(TPB), 0, stream, (const T*)dout,
                        (const T*)x0, (const T*)x1, (const T*)x2, wraw, (T*)d0, (T*)d1, (T*)d2,
                        dw_raw ? gacc : nullptr, numel / V, n);
   });
-  if (dw_raw) hipLaunchKernelGGL(fusion_wgrad_kernel, dim3(1), dim3(64), 0, stream, wraw, gacc, dw_raw, n);
+  if (dw_raw) hipLaunchKernelGGL(fusion_wgrad_kernel, dim3(1), dim3(256), 0, stream, wraw, gacc, nblk, dw_raw, n);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
 }
@@ -1624,7 +1640,7 @@ int sihl_blur_fuse(const void* a, const void* b, const void* c, const float* wra
   return SIHL_OK;
 }
 
-// fused (b != null): gacc 3 floats; plain blur (b == null): only da is produced
+// fused (b != null): gacc = SIHL_FUSION_GACC_FLOATS floats of scratch; plain blur (b == null): only da is produced
 // a_scale / a_shift: as in sihl_blur_fuse; `da` is then the gradient of a * scale + shift (what the producing conv
 // block's BatchNorm backward takes), the fusion-weight gradient uses the blurred affine value
 int sihl_blur_fuse_bwd(const void* dout, const void* a, const void* b, const void* c, const float* wraw,
@@ -1633,19 +1649,20 @@ int sihl_blur_fuse_bwd(const void* dout, const void* a, const void* b, const voi
   if (!dout || N <= 0 || H < 2 || W < 2 || (dw_raw && (!gacc || !b))) return SIHL_EARG;
   if ((a_scale != nullptr) != (a_shift != nullptr)) return SIHL_EARG;
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  if (dw_raw) { hipError_t e = hipMemsetAsync(gacc, 0, 3 * sizeof(float), stream); if (e) return (int)e; }
+  int nblk = 0;
   DISPATCH_DTYPE(dtype, {
     constexpr int V = 16 / sizeof(T);
     if (C % V) return SIHL_EARG;
+    nblk = grid_for((long)N * Ho * Wo * (C / V));
     if (b && (db || dc || dw_raw))
-      hipLaunchKernelGGL(blur_fuse_bwd_lo_kernel<T>, dim3(grid_for((long)N * Ho * Wo * (C / V))), dim3(TPB), 0,
+      hipLaunchKernelGGL(blur_fuse_bwd_lo_kernel<T>, dim3(nblk), dim3(TPB), 0,
                          stream, (const T*)dout, (const T*)a, (const T*)b, (const T*)c, wraw, a_scale, a_shift, (T*)db,
                          (T*)dc, dw_raw ? gacc : nullptr, N, H, W, Ho, Wo, C);
     if (da)
       hipLaunchKernelGGL(blur_adjoint_kernel<T>, dim3(grid_for((long)N * H * W * (C / V))), dim3(TPB), 0, stream,
                          (const T*)dout, b ? wraw : nullptr, (T*)da, N, H, W, Ho, Wo, C);
   });
-  if (dw_raw) hipLaunchKernelGGL(fusion_wgrad_kernel, dim3(1), dim3(64), 0, stream, wraw, gacc, dw_raw, 3);
+  if (dw_raw) hipLaunchKernelGGL(fusion_wgrad_kernel, dim3(1), dim3(256), 0, stream, wraw, gacc, nblk, dw_raw, 3);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
 }

@@ -61,6 +61,7 @@ def _sized(name: str, *args):
         v = _SIZES[key] = getattr(_C.lib(), name)(*args)
     return v
 
+FUSION_GACC_FLOATS = 4 * 4096  # SIHL_FUSION_GACC_FLOATS of include/sihl_hip.h: scratch of the fusion nodes' backward
 _SPLIT_TAIL_BWD = bool(os.environ.get("SIHL_SPLIT_TAIL_BWD"))
 _ATEN_STEM_WGRAD = bool(os.environ.get("SIHL_ATEN_STEM_WGRAD"))
 TAIL_MASK_BITS = os.environ.get("SIHL_TAIL_MASK_BITS", "1") != "0"  # A/B / test switch: 0 = the tail's backward re-reads y
@@ -913,7 +914,7 @@ class FuseUp2Fn(torch.autograd.Function):
         da = torch.empty_like(a) if need_a else None
         db = torch.empty_like(b) if need_b else None
         dw = torch.empty(2, dtype=torch.float32, device=b.device) if need_w else None
-        gacc = torch.empty(2, dtype=torch.float32, device=b.device) if need_w else None
+        gacc = torch.empty(FUSION_GACC_FLOATS, dtype=torch.float32, device=b.device) if need_w else None
         rc = _C.lib().sihl_fuse_up2_bwd(_p(dout), _p(a), _p(b), _p(wr), _p(da), _p(db), _p(dw), _p(gacc), N, H, W, C,
                                         _dt(b), _stream())
         check(rc, "sihl_fuse_up2_bwd")
@@ -954,7 +955,7 @@ class BlurFuseFn(torch.autograd.Function):
         db = torch.empty_like(dout) if (ctx.fused and need_b) else None
         dc = torch.empty_like(dout) if (ctx.fused and need_c) else None
         dw = torch.empty(3, dtype=torch.float32, device=dev) if (ctx.fused and need_w) else None
-        gacc = torch.empty(3, dtype=torch.float32, device=dev) if dw is not None else None
+        gacc = torch.empty(FUSION_GACC_FLOATS, dtype=torch.float32, device=dev) if dw is not None else None
         rc = _C.lib().sihl_blur_fuse_bwd(_p(dout), _p(a), _p(b), _p(c), _p(wr), _p(a_scale), _p(a_shift), _p(da), _p(db),
                                          _p(dc), _p(dw), _p(gacc), N, H, W, C, _dt(a), _stream())
         check(rc, "sihl_blur_fuse_bwd")
@@ -1008,7 +1009,7 @@ class FuseSumFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         ds = [torch.empty_like(x) if need[1 + i] else None for i, x in enumerate(xs)]
         dw = torch.empty(n, dtype=torch.float32, device=dout.device) if need[0] else None
-        gacc = torch.empty(3, dtype=torch.float32, device=dout.device) if need[0] else None
+        gacc = torch.empty(FUSION_GACC_FLOATS, dtype=torch.float32, device=dout.device) if need[0] else None
         rc = _C.lib().sihl_fuse_sum_bwd(_p(dout), _p(xs[0]), _p(xs[1]), _p(xs[2]) if n > 2 else None, _p(wr),
                                         _p(ds[0]), _p(ds[1]), _p(ds[2]) if n > 2 else None, _p(dw), _p(gacc),
                                         dout.numel(), n, _dt(dout), _stream())

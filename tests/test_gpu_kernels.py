@@ -147,6 +147,30 @@ def test_fuse_up2_and_blur(dtype, rtol, atol):
         _close(wd.grad, wr.grad, rtol * 5, atol * 5, "blur dw")
 
 
+def test_fusion_weight_gradients_are_bit_reproducible():
+    """The FastNormalizedFusion weight gradients (layers/bifpn.py:10-17: d softmax(w) . <dout, inputs>) of the fused
+    nodes' backward are sums over the whole tensor: per-workgroup partial rows added in a fixed order (no atomics), so
+    two runs on the same inputs agree bit for bit - on tensors large enough for thousands of workgroups."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(41)
+    a = torch.randn(4, 32, 48, 256, generator=g).to(DEV, torch.bfloat16)
+    b = torch.randn(4, 64, 96, 256, generator=g).to(DEV, torch.bfloat16)
+    c = torch.randn(4, 32, 48, 256, generator=g).to(DEV, torch.bfloat16)
+    cot_hi = torch.randn(4, 64, 96, 256, generator=g).to(DEV, torch.bfloat16)
+    cot_lo = torch.randn(4, 32, 48, 256, generator=g).to(DEV, torch.bfloat16)
+    runs = []
+    for _ in range(3):
+        w2 = torch.tensor([0.3, -0.2], device=DEV, requires_grad=True)
+        w3 = torch.tensor([0.1, 0.4, -0.3], device=DEV, requires_grad=True)
+        ops.fuse_up2(a.clone().requires_grad_(True), b.clone().requires_grad_(True), w2).backward(cot_hi)
+        ops.blur_fuse(b.clone().requires_grad_(True), a.clone().requires_grad_(True), c.clone().requires_grad_(True),
+                      w3).backward(cot_lo)
+        runs.append((w2.grad.clone(), w3.grad.clone()))
+        torch.randn(1 << 20, device=DEV).sum().item()  # other work in between
+    for r in runs[1:]:
+        assert torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1])
+
+
 @pytest.mark.parametrize("dtype,rtol,atol", DTYPES)
 def test_fusion_nodes_borders_and_odd_sizes(dtype, rtol, atol):
     """Forward of the two BiFPN fusion nodes (layers/bifpn.py:39-53: sihl_fuse_up2 / sihl_blur_fuse, one output row per
