@@ -336,6 +336,9 @@ int sihl_uafm_bwd(const void* dout, const void* x1, const void* x2, const float*
                   int H, int W, int C, int dtype, float* ws, long ws_bytes, hipStream_t stream);
 int sihl_softmax_max_resize(const void* logits, float* scores, long* classes, int N, int h, int w, int C, int H,
                             int W, int dtype, hipStream_t stream);
+/* acc: SIHL_CE_ACC_FLOATS floats - acc[0] = loss sum, acc[1] = valid-target count on return; the rest holds per-workgroup
+ * partial sums that are added in a fixed order (bit-reproducible; no initialisation needed). */
+#define SIHL_CE_ACC_FLOATS (2 + 2 * 2048)
 int sihl_ce_resize(const void* logits, const long* targets, long ignore_index, const float* inv_count, void* dl,
                    float* acc, int N, int h, int w, int C, int H, int W, int dtype, hipStream_t stream);
 

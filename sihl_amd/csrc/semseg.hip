@@ -127,7 +127,8 @@ __global__ void uafm_dpre_kernel(const T* __restrict__ dout, const T* __restrict
 }
 
 // dstats[pix][ci] = sum_taps dpre[pix - tap] * w[ci][tap]; dw[ci][ky][kx] += sum_pix dpre[pix]*stats[pix+tap][ci];
-// dbias += sum dpre.  gacc: 37 floats (36 weights + bias), zeroed by the launcher.
+// dbias += sum dpre.  gacc: one partial row of 40 floats (36 weights + bias) per workgroup, summed in workgroup order by
+// uafm_wgrad_finalize_kernel (no atomics: bit-reproducible).
 __global__ void uafm_alpha_bwd_kernel(const float* __restrict__ dpre, const float* __restrict__ stats,
                                       const float* __restrict__ w, float* __restrict__ dstats, float* gacc, int N,
                                       int H, int W) {
@@ -178,8 +179,18 @@ __global__ void uafm_alpha_bwd_kernel(const float* __restrict__ dpre, const floa
   if (threadIdx.x < 37) {
     float s = 0.f;
     for (int v = 0; v < TPB / 64; ++v) s += red[threadIdx.x][v];
-    atomicAdd(gacc + threadIdx.x, s);
+    gacc[(long)blockIdx.x * 40 + threadIdx.x] = s;
   }
+}
+
+__global__ void uafm_wgrad_finalize_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ dconv_w,
+                                           float* __restrict__ dconv_b) {
+  const int k = threadIdx.x;
+  if (k >= 37) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += part[(long)b * 40 + k];
+  if (k < 36) { if (dconv_w) dconv_w[k] = s; }
+  else if (dconv_b) dconv_b[0] = s;
 }
 
 // dx1 = alpha*dout + dstats.mean1/C + [c == argmax1]*dstats.max1 ; dx2 likewise with (1-alpha)
@@ -245,7 +256,8 @@ __global__ void softmax_max_resize_kernel(const T* __restrict__ logits, float* _
   }
 }
 
-// One wave per logit pixel.  acc[0] += sum over its valid target pixels of (lse - logit[target]); acc[1] += n_valid;
+// One wave per logit pixel.  Per workgroup: part[b] = (sum over its valid target pixels of (lse - logit[target]), n_valid),
+// summed in workgroup order by ce_finalize_kernel;
 // dl[pix][c] = n_valid*softmax_c - hist_c  (unscaled gradient of the SUMMED loss).
 template <typename T>
 __global__ void ce_resize_kernel(const T* __restrict__ logits, const long* __restrict__ targets, long ignore_index,
@@ -295,7 +307,22 @@ __global__ void ce_resize_kernel(const T* __restrict__ logits, const long* __res
       elem<T>::st(dl + p * C + c, (nv * expf(lg[c] - lse) - hist[c]) * dscale);
   }
   loss = wave_sum(loss);
-  if (lane == 0) { atomicAdd(acc, loss); atomicAdd(acc + 1, cnt); }
+  __shared__ float wsum[TPB / 64][2];
+  if (lane == 0) { wsum[wv][0] = loss; wsum[wv][1] = cnt; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    float t = 0.f;
+    for (int v = 0; v < TPB / 64; ++v) t += wsum[v][threadIdx.x];
+    acc[2 + 2 * (long)blockIdx.x + threadIdx.x] = t;
+  }
+}
+
+__global__ void ce_finalize_kernel(float* __restrict__ acc, int nblocks) {
+  if (threadIdx.x < 2) {
+    float t = 0.f;
+    for (int b = 0; b < nblocks; ++b) t += acc[2 + 2 * (long)b + threadIdx.x];
+    acc[threadIdx.x] = t;
+  }
 }
 
 inline int grid_for(long n) {
@@ -340,8 +367,9 @@ int sihl_uafm_fwd(const void* x1, const void* x2, const float* conv_w, const flo
   return SIHL_OK;
 }
 
-// ws: floats, at least 5*N*H*W + 37 (dpre, dstats, gacc).  dconv_w: 36 floats, dconv_b: 1 float (may be NULL).
-long sihl_uafm_bwd_ws_bytes(int N, int H, int W) { return ((long)N * H * W * 5 + 64) * (long)sizeof(float); }
+// ws: floats, at least 5*N*H*W + 512*40 (dpre, dstats, per-workgroup partial rows).  dconv_w: 36 floats, dconv_b: 1 float
+// (may be NULL).
+long sihl_uafm_bwd_ws_bytes(int N, int H, int W) { return ((long)N * H * W * 5 + 512 * 40) * (long)sizeof(float); }
 
 int sihl_uafm_bwd(const void* dout, const void* x1, const void* x2, const float* conv_w, const float* stats,
                   const int* arg, const float* alpha, void* dx1, void* dx2, float* dconv_w, float* dconv_b, int N,
@@ -352,20 +380,19 @@ int sihl_uafm_bwd(const void* dout, const void* x1, const void* x2, const float*
   float* dpre = ws;
   float* dstats = ws + npix;
   float* gacc = ws + npix * 5;
-  hipError_t e = hipMemsetAsync(gacc, 0, 37 * sizeof(float), stream);
-  if (e != hipSuccess) return (int)e;
+  const int nblk = grid_for(npix) > 512 ? 512 : grid_for(npix);
   DISPATCH_DTYPE(dtype, {
     constexpr int V = 16 / sizeof(T);
     if (C % V) return SIHL_EARG;
     hipLaunchKernelGGL(uafm_dpre_kernel<T>, dim3(grid_for_waves(npix)), dim3(TPB), 0, stream, (const T*)dout,
                        (const T*)x1, (const T*)x2, alpha, dpre, npix, C);
-    hipLaunchKernelGGL(uafm_alpha_bwd_kernel, dim3(grid_for(npix) > 512 ? 512 : grid_for(npix)), dim3(TPB), 0, stream,
+    hipLaunchKernelGGL(uafm_alpha_bwd_kernel, dim3(nblk), dim3(TPB), 0, stream,
                        (const float*)dpre, stats, conv_w, dstats, gacc, N, H, W);
     hipLaunchKernelGGL(uafm_dx_kernel<T>, dim3(grid_for(npix * (C / V))), dim3(TPB), 0, stream, (const T*)dout, alpha,
                        (const float*)dstats, arg, (T*)dx1, (T*)dx2, npix * (C / V), C / V);
   });
-  if (dconv_w) { e = hipMemcpyAsync(dconv_w, gacc, 36 * sizeof(float), hipMemcpyDeviceToDevice, stream); if (e) return (int)e; }
-  if (dconv_b) { e = hipMemcpyAsync(dconv_b, gacc + 36, sizeof(float), hipMemcpyDeviceToDevice, stream); if (e) return (int)e; }
+  if (dconv_w || dconv_b)
+    hipLaunchKernelGGL(uafm_wgrad_finalize_kernel, dim3(1), dim3(64), 0, stream, (const float*)gacc, nblk, dconv_w, dconv_b);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
 }
@@ -383,18 +410,19 @@ int sihl_softmax_max_resize(const void* logits, float* scores, long* classes, in
 }
 
 // Cross-entropy of nearest-resized logits against targets int64 [N][H][W] with ignore_index.
-// acc: 2 floats (loss sum, valid count), zeroed here; dl [N][h][w][C] = d(sum loss)/d logits * inv_count[0]
+// acc: SIHL_CE_ACC_FLOATS floats; acc[0] = loss sum, acc[1] = valid count on return (the rest: per-workgroup partials, summed
+// in a fixed order - bit-reproducible); dl [N][h][w][C] = d(sum loss)/d logits * inv_count[0]
 // (inv_count: device scalar = 1 / #valid targets for the mean reduction; NULL = 1).
 int sihl_ce_resize(const void* logits, const long* targets, long ignore_index, const float* inv_count, void* dl,
                    float* acc, int N, int h, int w, int C, int H, int W, int dtype, hipStream_t stream) {
   if (!logits || !targets || !dl || !acc || N <= 0 || h <= 0 || w <= 0 || C <= 0 || C > 4096) return SIHL_EARG;
-  hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(float), stream);
-  if (e != hipSuccess) return (int)e;
   const size_t lds = (size_t)(TPB / 64) * 2 * C * sizeof(float);
+  const int nblk = grid_for_waves((long)N * h * w);
   DISPATCH_DTYPE(dtype, {
-    hipLaunchKernelGGL(ce_resize_kernel<T>, dim3(grid_for_waves((long)N * h * w)), dim3(TPB), lds, stream,
+    hipLaunchKernelGGL(ce_resize_kernel<T>, dim3(nblk), dim3(TPB), lds, stream,
                        (const T*)logits, targets, ignore_index, inv_count, (T*)dl, acc, N, h, w, C, H, W);
   });
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, stream, acc, nblk);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
 }

@@ -1503,7 +1503,7 @@ class CEResizeFn(torch.autograd.Function):
         H, W = tg.shape[1:]
         inv_count = 1.0 / (tg != ignore_index).sum().to(torch.float32).reshape(1)  # device scalar, no host sync
         dl = torch.empty_like(lg)
-        acc = torch.empty(2, dtype=torch.float32, device=lg.device)
+        acc = torch.empty(2 + 2 * 2048, dtype=torch.float32, device=lg.device)  # SIHL_CE_ACC_FLOATS
         rc = _C.lib().sihl_ce_resize(_p(lg), _p(tg), int(ignore_index), _p(inv_count), _p(dl), _p(acc), N, h, w, C, H,
                                      W, _dt(lg), _stream())
         check(rc, "sihl_ce_resize")
