@@ -23,6 +23,11 @@
 //     multiply alone), more than the finishing launch's 5 us: kernel boundaries are the cheaper coherence point here.)
 //   * an unsplit launch (P5) runs the epilogue itself (bias -> [stats] -> affine -> act -> [stats] -> affine, BatchNorm
 //     partial row per 128 pixels, as conv_igemm_impl.h) on 8-channel vectors with 16-byte output stores.
+//
+// Not for the thin 3x3 convs of the ResNet trunk (tried, round 3: instantiated for 128x128 maps with 64 channels and 64x64 with
+// 128, parity-green): 148 us against 80-89 for the general kernel on layer1's 64 -> 64, 98 against 50 on layer2's 128 -> 128.
+// At thousands of tiles per launch the general kernel's small single-stage tiles (3-4 workgroups per CU hiding each other's
+// load and store phases) beat one 125-147 KiB workgroup per CU that loads its patch, then multiplies.
 #include "common.h"
 #include "conv_params.h"
 #include "conv_tuning.h"
