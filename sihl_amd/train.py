@@ -354,6 +354,22 @@ class Trainer:
             metrics.update({f"head{i}/train/{k}": v for k, v in m.items()})
         return torch.stack(losses).sum(), metrics
 
+    def _clip_gradients(self) -> None:
+        """torch.nn.utils.clip_grad_norm_(parameters, max_norm) (the reference's Lightning ``gradient_clip_val``) - the same
+        multi-tensor launches in the same order (per-tensor 2-norms, the norm of their stack, coefficient clamped to 1, one
+        in-place multiply: bit-identical results), without the per-call grouping by device and dtype: ~0.5 ms of host time
+        per step on 320 parameters.  Mixed devices / dtypes take the library routine."""
+        grads = [p.grad for p in self._params if p.grad is not None]
+        if not grads:
+            return
+        g0 = grads[0]
+        if any(g.device != g0.device or g.dtype != g0.dtype or g.is_sparse for g in grads):
+            torch.nn.utils.clip_grad_norm_([p for p in self._params if p.grad is not None], self.grad_clip_norm)
+            return
+        total = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads, 2.0)), 2.0)
+        coef = torch.clamp(self.grad_clip_norm / (total + 1e-6), max=1.0)
+        torch._foreach_mul_(grads, coef)
+
     def _backward(self, loss: Tensor) -> None:
         if self.wgrad_stream == "off" or not loss.is_cuda or torch.cuda.is_current_stream_capturing():
             loss.backward()
@@ -369,8 +385,7 @@ class Trainer:
         self._backward(loss)
         self.averager.finish()
         if self.grad_clip_norm is not None:
-            torch.nn.utils.clip_grad_norm_([p for p in self._params if p.grad is not None],
-                                           self.grad_clip_norm)
+            self._clip_gradients()
         self.optimizer.step()
         if self.prepared is not None:
             self.prepared.refresh()
@@ -387,8 +402,7 @@ class Trainer:
             loss, metrics = self.forward_loss(static_images, static_targets)
             self._backward(loss)
             if self.grad_clip_norm is not None:
-                torch.nn.utils.clip_grad_norm_([p for p in self._params if p.grad is not None],
-                                               self.grad_clip_norm)
+                self._clip_gradients()
             self.optimizer.step()
             if self.prepared is not None:
                 self.prepared.refresh()

@@ -37,7 +37,7 @@ for _ in range(N):
     loss, metrics = tr.forward_loss(images, targets); t = lap("forward_loss", t)
     tr._backward(loss); t = lap("backward (+ join)", t)
     tr.averager.finish(); t = lap("averager.finish", t)
-    torch.nn.utils.clip_grad_norm_([p for p in tr._params if p.grad is not None], tr.grad_clip_norm); t = lap("clip_grad_norm_", t)
+    tr._clip_gradients(); t = lap("clip gradients", t)
     tr.optimizer.step(); t = lap("optimizer.step", t)
     tr.prepared.refresh(); t = lap("prepared.refresh", t)
     tr._step_scheduler(); t = lap("scheduler", t)
