@@ -43,14 +43,20 @@ class _ConvBlock(nn.Sequential):
     def forward_nhwc(self, x: Tensor, defer=None) -> Tensor:
         """defer: an ops.DeferredAffine when the only consumer of the result is a blur-pool that takes the BatchNorm
         affine over (AntialiasedDownscaler, BiFPNLayer)."""
-        conv, bn = self._parts()
-        if conv.groups != 1 or conv.padding_mode != "zeros":
-            raise NotImplementedError("sihl_amd conv kernels cover groups=1, zero padding")
-        if any(isinstance(m, (nn.GroupNorm, nn.Softplus, nn.Softmax)) for m in self):
-            raise NotImplementedError("GroupNorm / softplus / softmax blocks are outside the HIP hot path")
-        (sh, sw), (ph, pw), (dh, dw) = conv.stride, conv.padding, conv.dilation
-        if sh != sw or ph != pw or dh != dw:
-            raise NotImplementedError("square stride / padding / dilation only")
+        plan = self.__dict__.get("_sihl_plan")
+        if plan is None:  # the block's structure is fixed after construction: checked once (~5 us x 140 blocks per forward)
+            conv, bn = self._parts()
+            if conv.groups != 1 or conv.padding_mode != "zeros":
+                raise NotImplementedError("sihl_amd conv kernels cover groups=1, zero padding")
+            if any(isinstance(m, (nn.GroupNorm, nn.Softplus, nn.Softmax)) for m in self):
+                raise NotImplementedError("GroupNorm / softplus / softmax blocks are outside the HIP hot path")
+            (sh, sw), (ph, pw), (dh, dw) = conv.stride, conv.padding, conv.dilation
+            if sh != sw or ph != pw or dh != dw:
+                raise NotImplementedError("square stride / padding / dilation only")
+            if bn is not None and (bn.momentum is None or not bn.track_running_stats or not bn.affine):
+                raise NotImplementedError("BatchNorm2d with default affine / running-stat settings only")
+            plan = self.__dict__["_sihl_plan"] = (conv, bn, sh, ph, dh)
+        conv, bn, sh, ph, dh = plan
         weight, bias = conv.weight, conv.bias
         vec = _vec(x.dtype)
         cout = weight.shape[0]
@@ -65,8 +71,6 @@ class _ConvBlock(nn.Sequential):
             weight = F.pad(weight, (0, 0, 0, 0, 0, 0, 0, _pad_to(cout, vec) - cout))
             bias = F.pad(bias, (0, _pad_to(cout, vec) - cout)) if bias is not None else None
         if bn is not None:
-            if bn.momentum is None or not bn.track_running_stats or not bn.affine:
-                raise NotImplementedError("BatchNorm2d with default affine / running-stat settings only")
             if self.training:
                 ops.bump_counter(bn.num_batches_tracked)
             y = ops.conv_block(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, stride=sh,
