@@ -75,6 +75,17 @@ def usable_cores():
     return cores
 
 
+def cpu_model():
+    """The host CPU's model name (SURVEY 8d asks for it next to the core count)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(sample_batch, size, iters=5, warm=2):
     """The oracle (CPU port of the reference path) on a bounded sample: same model, same step, fp32; median of `iters`
     steps after `warm` warm-ups.  The sample is a smaller BATCH of the same 512x512 workload (images are
@@ -89,6 +100,8 @@ def cpu_baseline(sample_batch, size, iters=5, warm=2):
                                ObjectDetection=oracle.ObjectDetection, SihlModel=oracle.SihlModel)
     cores = usable_cores()
     torch.set_num_threads(cores)
+    if sample_batch >= 16:  # the full batch costs ~8 s per step: one warm-up and three timed steps keep the leg near 30 s
+        iters, warm = min(iters, 3), min(warm, 1)
     model = build_model(ns, "cpu")
     trainer = Trainer(model, lr=1e-4, weight_decay=1e-4, backbone_lr_factor=0.1)
     images, targets = synthetic_batch(sample_batch, size, "cpu", seed=0)
@@ -100,7 +113,7 @@ def cpu_baseline(sample_batch, size, iters=5, warm=2):
         trainer.step(images, targets)
         times.append(time.perf_counter() - t0)
     dt = sorted(times)[len(times) // 2]
-    return {"value": sample_batch / dt, "unit": "images/s", "cores": cores, "kind": "port",
+    return {"value": sample_batch / dt, "unit": "images/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
             "sample": f"oracle (CPU fp32 restatement) fwd+bwd+step, bs={sample_batch} of the same {size}x{size} "
                       f"workload, median of {iters} steps after {warm} warm-ups ({dt:.2f} s/step)"}
 
@@ -129,7 +142,7 @@ def north_star_cpu_baseline(sample_batch, size, iters=5, warm=2):
             if i >= warm:
                 times.append(time.perf_counter() - t0)
     dt = sorted(times)[len(times) // 2]
-    return {"value": sample_batch / dt, "unit": "images/s", "cores": cores, "kind": "port",
+    return {"value": sample_batch / dt, "unit": "images/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
             "sample": f"oracle BiFPN + ObjectDetection.forward (CPU fp32), bs={sample_batch} of the same {size}x{size} level "
                       f"list, median of {iters} forwards after {warm} warm-ups ({dt:.2f} s/forward)"}
 
@@ -281,7 +294,7 @@ def main():
                     help="debugging only, with --graph: stream mode of the eager warm-up steps before the capture (the "
                          "round-1 fault needed 'all'; a graph Trainer otherwise never uses a second stream)")
     ap.add_argument("--krot", type=int, default=-1,
-                    help="A/B: sihl_conv2d_krot value (stage stride between workgroups' K-loop starts; + 1000 x minimum stages)")
+                    help="A/B, tuning builds only: sihl_conv2d_krot value (stage stride between workgroups' K-loop starts; + 1000 x minimum stages)")
     ap.add_argument("--main-priority", type=int, default=0,
                     help="A/B: run the step on a user stream of this HIP priority (-1 = high) instead of the default stream")
     ap.add_argument("--no-fused-loss", action="store_true",
@@ -378,8 +391,8 @@ def main():
         with torch.cuda.stream(extra):
             _dummy = torch.zeros(1024, device=device).add_(1)
         torch.cuda.synchronize()
-    if args.krot >= 0:
-        _C.lib().sihl_conv2d_krot(args.krot)
+    if args.krot >= 0 and _C.lib().sihl_conv2d_krot(args.krot) != 0:
+        raise SystemExit("--krot needs a `make TUNING=1` library (SIHL_HIP_LIB=...): the shipped one has no tuning state")
     if args.main_priority:
         torch.cuda.synchronize()
         _main = torch.cuda.Stream(device=device, priority=args.main_priority)

@@ -13,9 +13,12 @@
  *     accumulation).  Statistics, norm parameters and every gradient of a parameter are fp32.
  *   - ownership: every buffer is caller-owned device memory (PyTorch's caching allocator in sihl_amd);
  *     kernels never allocate.  Scratch comes in through (ws, ws_bytes); the *_ws_bytes helpers size it.
- *   - streams: every launch goes to the hipStream_t argument, no implicit synchronisation, no global
- *     mutable state except the opt-in launch profiler and the test / tuning hooks (sihl_conv2d_*_override,
- *     *_enable, *_force_*, sihl_conv2d_debug: never called by the product path); entries are re-entrant.
+ *   - streams: every launch goes to the hipStream_t argument, no implicit synchronisation; entries are
+ *     re-entrant.  Process-wide switches, none of them touched by the product path: the opt-in launch profiler,
+ *     the TEST hooks that select between two parity-tested kernels for the same result (sihl_conv2d_tile_override,
+ *     *_enable, *_force_*), and the TUNING setters (sihl_conv2d_debug, sihl_conv2d_nbuf_override,
+ *     sihl_conv2d_rules_off, sihl_conv2d_krot, sihl_mlp_debug, sihl_mlp_rows_debug), which are live only in a
+ *     `make TUNING=1` library: the shipped library stores nothing and answers SIHL_EARG to any non-default value.
  *   - errors: 0 = ok, SIHL_EARG (-1) = bad argument / unsupported shape, SIHL_EWS (-2) = workspace too
  *     small, > 0 = hipError_t.  Nothing throws across the ABI.
  */
@@ -53,8 +56,9 @@ int sihl_conv2d_stat_rows(long M);
 int sihl_conv2d_force_register_staging(int on);
 /* Tuning hook: pixel-tile size of the LDS-DMA kernel for Cout > 128 (0 = heuristic, 128 or 256). */
 int sihl_conv2d_tile_override(int bm);
-int sihl_conv2d_nbuf_override(int n); /* tuning hook: LDS stages of the narrow-tile kernels, 0 = default */
-/* Tuning ablation of the LDS-DMA kernel (results are INVALID when non-zero): 1 = no in-loop DMA, 2 = no ds_read/MFMA. */
+int sihl_conv2d_nbuf_override(int n); /* TUNING builds only: LDS stages of the narrow-tile kernels, 0 = default */
+/* TUNING builds only - ablation of the LDS-DMA kernel (results are INVALID when non-zero): 1 = no in-loop DMA,
+ * 2 = no ds_read/MFMA.  The shipped library refuses any non-zero mode (SIHL_EARG). */
 int sihl_conv2d_debug(int mode);
 int sihl_conv2d_strided_classes_enable(int on); /* test hook: 0 = zero-dilated read for 3x3 stride-2 dgrads */
 int sihl_conv2d_fwd(const void* in, const void* wt, const float* bias, void* out, int N, int H, int W, int Cin,
@@ -90,8 +94,8 @@ int sihl_conv2d_dgrad_add(const void* dout, const void* wt_t, void* din, const v
                           long ws_bytes, hipStream_t stream);
 int sihl_conv2d_splitk_enable(int on); /* tuning / test hook */
 int sihl_conv2d_small_enable(int on);  /* tuning / test hook: 0 = 3x3 convs of the small pyramid levels on the general kernel, not csrc/conv_small.hip */
-int sihl_conv2d_rules_off(int mask);   /* tuning hook: disable individual dispatch rules */
-int sihl_conv2d_krot(int n);           /* tuning hook: stage stride between neighbouring workgroups' K-loop starts (100000 * log2(group) + 1000 * min_stages + stride; default 200013 = groups of 4 workgroups share a start, stride 13; 0 = lockstep) */
+int sihl_conv2d_rules_off(int mask);   /* TUNING builds only: disable individual dispatch rules */
+int sihl_conv2d_krot(int n);           /* TUNING builds only: stage stride between neighbouring workgroups' K-loop starts (100000 * log2(group) + 1000 * min_stages + stride; default 200013 = groups of 4 workgroups share a start, stride 13; 0 = lockstep) */
 
 /* Weight gradient (autograd of Conv2d.weight / Linear.weight): dw fp32 [Cout][KH][KW][Cin];
  * accumulate != 0 adds into dw.  Cin, Cout % vector == 0. */

@@ -25,11 +25,20 @@ int sihl_conv2d_dgrad_add(const void* dout, const void* wt_t, void* din, const v
 // Test hook: 1 = use the register-staged loader instead of LDS-DMA (both are kept parity-tested).
 int sihl_conv2d_force_register_staging(int on) { g_force_reg = on != 0; return 0; }
 
+// The ablation / tuning setters below change process-wide state and (sihl_conv2d_debug) make results INVALID: they exist
+// only in `make TUNING=1` libraries.  The shipped library keeps the symbols (one binding for both builds) but stores
+// nothing: a non-default request is refused with SIHL_EARG.
+#ifdef SIHL_TUNING
+#define SIHL_TUNING_SET(var, value) do { (var) = (value); return SIHL_OK; } while (0)
+#else
+#define SIHL_TUNING_SET(var, value) do { return (value) == (var) ? SIHL_OK : SIHL_EARG; } while (0)
+#endif
+
 // Tuning ablation (results invalid when non-zero): 1 = skip the in-loop DMA, 2 = skip ds_read/MFMA.
-int sihl_conv2d_debug(int mode) { g_dbg = mode; return 0; }
+int sihl_conv2d_debug(int mode) { SIHL_TUNING_SET(g_dbg, mode); }
 
 // Tuning hook: LDS stages of the narrow-tile LDS-DMA kernels (0 = default, 2..4).
-int sihl_conv2d_nbuf_override(int n) { g_nbuf = n; return 0; }
+int sihl_conv2d_nbuf_override(int n) { SIHL_TUNING_SET(g_nbuf, n); }
 
 // Tuning hook: force the pixel-tile size of the LDS-DMA kernel (0 = heuristic, 128, 256).
 int sihl_conv2d_tile_override(int bm) { g_tile_override = bm; return 0; }
@@ -49,7 +58,7 @@ long sihl_conv2d_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW
 }
 
 // Tuning hook: switch individual dispatch rules off (bit 0: single-stage narrow tiles, bit 1: thin pointwise -> 128x128).
-int sihl_conv2d_rules_off(int mask) { g_rules_off = mask; return 0; }
+int sihl_conv2d_rules_off(int mask) { SIHL_TUNING_SET(g_rules_off, mask); }
 
 // Tuning / test hook: 0 = the small pyramid levels' 3x3 convs take the general kernel instead of conv_small.hip.
 int sihl_conv2d_small_enable(int on) { sihl_small_set_enabled(on != 0); return 0; }
@@ -57,7 +66,7 @@ int sihl_conv2d_small_enable(int on) { sihl_small_set_enabled(on != 0); return 0
 // Tuning hook: 100000 * log2(group) + 1000 * min_stages + stride - the stage stride between the K-loop starts of
 // neighbouring GROUPS of workgroups (default 200013: groups of 4 share a start and with it their L2 fills, stride 13;
 // 0 = lockstep).
-int sihl_conv2d_krot(int n) { g_krot = n < 0 ? 0 : n; return 0; }
+int sihl_conv2d_krot(int n) { SIHL_TUNING_SET(g_krot, n < 0 ? 0 : n); }
 
 // Tuning / test hook: 0 disables split-K.
 int sihl_conv2d_splitk_enable(int on) { g_splitk = on != 0; return 0; }

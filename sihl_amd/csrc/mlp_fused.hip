@@ -380,7 +380,11 @@ int sihl_mlp_stages(int n) {
 }
 
 // Tuning ablation (SIHL_TUNING builds only; results invalid when non-zero): see MlpParams::dbg.
+#ifdef SIHL_TUNING
 int sihl_mlp_debug(int mode) { g_mlp_dbg = mode; return SIHL_OK; }
+#else
+int sihl_mlp_debug(int mode) { return mode == 0 ? SIHL_OK : SIHL_EARG; }  // the shipped library has no ablation state
+#endif
 
 // Diagnostic builds (-DSIHL_MLP_STAMPS): device buffer of 64 x u64 that workgroup 0 fills with its s_memtime marks.
 int sihl_mlp_stamps(void* buf) { g_mlp_stamps = (unsigned long long*)buf; return SIHL_OK; }

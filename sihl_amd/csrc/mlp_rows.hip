@@ -332,7 +332,11 @@ int sihl_mlp_rows_supported(long rows, int Cin, int C, int Cout, int nhidden, in
 }
 
 // Tuning ablation (`make TUNING=1` builds only; results invalid when non-zero): see MlpRowsParams::dbg.
+#ifdef SIHL_TUNING
 int sihl_mlp_rows_debug(int mode) { g_mlp_rows_dbg = mode; return SIHL_OK; }
+#else
+int sihl_mlp_rows_debug(int mode) { return mode == 0 ? SIHL_OK : SIHL_EARG; }  // the shipped library has no ablation state
+#endif
 
 // The K order sihl_mlp_rows_fwd wants for the weights of layers >= 1: w_out [Cout][K] from w_in [Cout][K] (bf16, K a
 // multiple of 16), inside each group of 16 input channels [0-3, 8-11, 4-7, 12-15].  Its own inverse.

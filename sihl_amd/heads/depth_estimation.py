@@ -81,7 +81,31 @@ class DepthEstimation(SemanticSegmentation):
         hist_loss = torch.stack(hist).mean()
         return pix_loss + hist_loss, {"pixel_loss": pix_loss, "hist_loss": hist_loss}
 
+    def on_validation_start(self) -> None:
+        """The reference keeps a MeanMetric of the loss and torchmetrics' MeanAbsoluteError / MeanSquaredError(squared=False)
+        over the masked pixels (depth_estimation.py:124-127); here: four device-side accumulators, read once at the end."""
+        self._val_losses: List[Tensor] = []
+        self._val_acc = None  # [sum |err|, sum err^2, count] over every masked pixel seen, float64 on the device
+
     def validation_step(self, inputs: List[Tensor], targets: Tensor, masks: Tensor):
-        loss, _ = self.training_step(inputs, targets, masks)
+        with torch.no_grad():
+            loss, _ = self.training_step(inputs, targets, masks)
+            depth = self.forward(inputs)  # (B, H, W), denormalised
+            m = masks.to(depth.device)
+            err = (depth - targets.to(depth.device).float())[m].double()
+            acc = torch.stack([err.abs().sum(), (err * err).sum(), m.sum().double()])
+            self._val_acc = acc if self._val_acc is None else self._val_acc + acc
         self._val_losses.append(loss.detach())
         return loss, {}
+
+    def on_validation_end(self) -> Dict[str, float]:
+        """{"loss", "rmse", "mae"} as the reference (depth_estimation.py:141-146); NaN losses are ignored in the mean like
+        MeanMetric(nan_strategy="ignore")."""
+        out = {"loss": float("nan"), "rmse": float("nan"), "mae": float("nan")}
+        if self._val_losses:
+            out["loss"] = torch.nanmean(torch.stack(self._val_losses).float()).item()
+        if self._val_acc is not None:
+            abs_sum, sq_sum, count = self._val_acc.tolist()
+            if count > 0:
+                out["mae"], out["rmse"] = abs_sum / count, (sq_sum / count) ** 0.5
+        return out

@@ -21,10 +21,16 @@ def _parts(mlp):
     return linears, norms, rest, act
 
 
+def _drops(mlp) -> bool:
+    """True when this MLP would really drop activations now (training mode with a Dropout of p > 0): the fused kernels have
+    no dropout, and the layer-by-layer path refuses that case loudly instead of skipping it."""
+    return mlp.training and any(isinstance(m, nn.Dropout) and m.p > 0 for m in mlp)
+
+
 def forward_many(mlps, x: Tensor):
     """[m(x) for m in mlps] for MLPs that read the same rows - in inference as ONE launch when the register kernel covers
     them all (ops.mlp_fused_multi), else one by one."""
-    if FUSE_WHOLE_MLP and not torch.is_grad_enabled() and len(mlps) > 1:
+    if FUSE_WHOLE_MLP and not torch.is_grad_enabled() and len(mlps) > 1 and not any(_drops(m) for m in mlps):
         lead = x.shape[:-1]
         h = x.reshape(-1, x.shape[-1])
         parts = [_parts(m) for m in mlps]
@@ -58,7 +64,7 @@ class MLP(nn.Sequential):
         lead = x.shape[:-1]
         h = x.reshape(-1, x.shape[-1])
         mods = list(self)
-        if FUSE_WHOLE_MLP and not torch.is_grad_enabled():
+        if FUSE_WHOLE_MLP and not torch.is_grad_enabled() and not _drops(self):
             # inference: the whole chain in one launch, activations resident in LDS between the layers (ops.mlp_fused)
             linears = [m for m in mods if isinstance(m, nn.Linear)]
             norms = [m for m in mods if isinstance(m, nn.LayerNorm)]

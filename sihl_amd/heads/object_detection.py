@@ -238,13 +238,16 @@ class ObjectDetection(nn.Module):
         True / G False - made once per device and grown on demand (device-side fills: no upload)."""
         key = str(device)
         c = ObjectDetection._PAD_CONST.get(key)
-        if c is None or c[0].shape[0] < G or torch.cuda.is_current_stream_capturing():
+        # (asked of CUDA tensors only: on a box without a HIP device the query itself raises, and on a GPU box a CPU call
+        # would initialise the GPU as a side effect)
+        capturing = torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing()
+        if c is None or c[0].shape[0] < G or capturing:
             n = max(G, 64)
             box = torch.zeros((n, 4), device=device)
             box[:, 2:] = 1.0
             c = (box, torch.zeros(n, device=device, dtype=torch.int64), torch.ones(n, device=device, dtype=torch.bool),
                  torch.zeros(n, device=device, dtype=torch.bool))
-            if not torch.cuda.is_current_stream_capturing():  # constants made inside a capture live in the graph's pool
+            if not capturing:  # constants made inside a capture live in the graph's pool
                 ObjectDetection._PAD_CONST[key] = c
         return c
 

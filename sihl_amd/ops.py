@@ -188,9 +188,11 @@ def _guard_shared_parameters(keys) -> None:
     appearance on, the main stream waits for the side stream before the node returns.  (A parameter used once is handed to
     AccumulateGrad as it is, no kernel: no wait - the common case costs a set lookup.)"""
     side = _SIDE
-    if side is None or not side.dirty:
+    if side is None:
         return
-    if any(k in side.seen for k in keys):
+    # (a clean side stream has nothing to wait for, but the keys are remembered all the same: in "small" mode a shared
+    # module's FIRST weight gradient can run on the main stream with nothing yet queued on the side stream)
+    if side.dirty and any(k in side.seen for k in keys):
         torch.cuda.current_stream().wait_stream(side.stream)
     side.seen.update(keys)
 
@@ -242,7 +244,7 @@ def weight_khwc(w: Tensor, dtype: torch.dtype) -> Tensor:
         # inference outside a Trainer (model.eval()(x) in bf16 with no PreparedWeights): the operand copy is made once per
         # weight version, not once per forward (~60 cast launches per BiFPN + head forward otherwise).  Same key as
         # PreparedWeights: storage address + torch's version counter (writes through .data do not bump it).
-        key = (dtype, w.data_ptr(), w._version)
+        key = (dtype, w.data_ptr(), w._version, _PARAM_GEN)
         hit = getattr(w, "_sihl_cast", None)
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -424,6 +426,16 @@ def bn_finalize(stats: Tensor, count: int, gamma, beta, eps, momentum, running_m
 
 
 _BN_STATS_GEN = 0  # bumped whenever a sihl kernel rewrites running statistics (raw pointers: no version-counter bump)
+_PARAM_GEN = 0  # bumped by Trainer.step after EVERY optimisation step, eager or HIP-graph replay
+
+
+def bump_param_generation() -> None:
+    """Tell the inference-side caches (eval BatchNorm affines, fp32 -> bf16 operand casts, MLP pointer plans) that parameters
+    and running statistics may have changed behind torch's version counters: a HIP-graph replay updates weights, gamma /
+    beta and running statistics by raw pointer, so neither ``tensor._version`` nor ``_BN_STATS_GEN`` (bumped at capture
+    only) moves.  Every cache key below holds this count."""
+    global _PARAM_GEN
+    _PARAM_GEN += 1
 
 
 def bn_eval_affine(gamma, beta, running_mean, running_var, eps):
@@ -433,7 +445,7 @@ def bn_eval_affine(gamma, beta, running_mean, running_var, eps):
     holds the storage addresses and torch's version counters of all four tensors (in-place ops, ``copy_`` and
     ``load_state_dict`` bump those; writes through ``.data`` do not - same contract as PreparedWeights) plus a generation
     count that every training-mode statistics update of this library bumps."""
-    key = (_BN_STATS_GEN, eps, running_mean.data_ptr(), running_mean._version, running_var.data_ptr(), running_var._version,
+    key = (_BN_STATS_GEN, _PARAM_GEN, eps, running_mean.data_ptr(), running_mean._version, running_var.data_ptr(), running_var._version,
            None if gamma is None else (gamma.data_ptr(), gamma._version),
            None if beta is None else (beta.data_ptr(), beta._version))
     hit = getattr(running_mean, "_sihl_eval_affine", None)
@@ -1201,7 +1213,7 @@ class _MLPPlan:
 def _mlp_plan(linears, norms, dtype):
     key = tuple((m.weight.data_ptr(), m.weight._version, getattr(getattr(m.weight, "_sihl_prepared", None), "version", None),
                  0 if m.bias is None else m.bias.data_ptr()) for m in linears) + \
-        tuple((n.weight.data_ptr(), n.bias.data_ptr()) for n in norms) + (MLP_KERNEL,)
+        tuple((n.weight.data_ptr(), n.bias.data_ptr()) for n in norms) + (MLP_KERNEL, _PARAM_GEN)
     plan = getattr(linears[0], "_sihl_mlp_plan", None)
     if plan is not None and plan.key == key:
         return plan
@@ -1229,7 +1241,10 @@ def _mlp_plan(linears, norms, dtype):
         keep = keep + rows_w
         plan.w_rows = (ctypes.c_void_p * n)(*[w.data_ptr() for w in rows_w])
     plan.keep, plan.key = keep, key
-    if prepared(linears[0].weight, dtype) is not None or not torch.is_grad_enabled():
+    # not stored during a stream capture (same rule as weight_khwc / bn_eval_affine): the permuted copies would live in the
+    # graph's private pool and sihl_mlp_permute_k would only have been RECORDED, not run, when a later eager call reads them
+    if (prepared(linears[0].weight, dtype) is not None or not torch.is_grad_enabled()) \
+            and not torch.cuda.is_current_stream_capturing():
         linears[0]._sihl_mlp_plan = plan  # (casts made on the fly are cached too: the key holds the master weight's version)
     return plan
 

@@ -141,7 +141,7 @@ class GradientAverager:
         for b in self.buckets:
             if b["work"] is None:  # some parameter of this bucket got no gradient this step
                 self._launch(b)
-        timed = self.buckets[0]["flat"].is_cuda
+        timed = bool(self.buckets) and self.buckets[0]["flat"].is_cuda
         if timed:  # how long the step's stream stands still for the collectives (read back lazily: wait_ms())
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
@@ -412,6 +412,11 @@ class Trainer:
     def step(self, images: Tensor, targets: List[Any]):
         if not self.model.training:  # (Module.train() walks every submodule: 2 ms of host time per step when unconditional)
             self.model.train()
+        if images.is_cuda:
+            from sihl_amd import ops
+            # whatever path runs below rewrites parameters / running statistics, a graph replay by raw pointer: the eval-side
+            # caches (BatchNorm affines, operand casts, MLP plans) must not survive it
+            ops.bump_param_generation()
         if not self.use_graph:
             return self._eager_step(images, targets)
         leaves = [images] + _tree_tensors(targets, [])

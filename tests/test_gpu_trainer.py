@@ -271,3 +271,47 @@ def test_two_stream_step_reaches_allocator_steady_state():
     st1 = torch.cuda.memory_stats()
     assert st1["num_device_alloc"] - st0["num_device_alloc"] <= 2, (st0["num_device_alloc"], st1["num_device_alloc"])
     assert st1["reserved_bytes.all.current"] <= st0["reserved_bytes.all.current"] * 1.05 + (64 << 20)
+
+
+@pytest.mark.parametrize("amp", [None, torch.bfloat16])
+def test_eval_after_graph_replays_sees_the_trained_weights(amp):
+    """Round-3 advisor finding: a HIP-graph replay rewrites weights, gamma / beta and running statistics by raw pointer, so
+    the inference-side caches (eval BatchNorm affines, operand casts, MLP plans - keyed on tensor versions) went stale in a
+    train -> validate -> train -> validate loop.  Trainer.step now bumps a parameter generation the cache keys hold: eval
+    after replays must equal the eval of an eagerly trained twin, both times."""
+    from sihl_amd.train import Trainer
+    ref_model = _model()
+    graph_model = copy.deepcopy(ref_model)
+    eager = Trainer(ref_model, lr=1e-3, grad_clip_norm=0.1, autocast_dtype=amp)
+    graphed = Trainer(graph_model, lr=1e-3, grad_clip_norm=0.1, autocast_dtype=amp, graph=True)
+    probe, _ = _batch(99, (1, 1, 1))
+
+    def evaluate(model):
+        model.eval()
+        with torch.no_grad(), torch.autocast("cuda", dtype=amp or torch.float32, enabled=amp is not None):
+            levels = model.backbone(probe)
+            if amp is not None:
+                levels = [t if i == 0 else t.to(amp) for i, t in enumerate(levels)]
+            feats = model.neck(levels)
+            head = model.heads[0]
+            flat = head._flat_features(feats) if hasattr(head, "_flat_features") else None
+            out = head(feats)
+        model.train()
+        return [feats[-1].float().clone(), out[1].float().clone()] + ([] if flat is None else [flat.float().clone()])
+
+    step = 0
+    prev = None
+    for phase in range(2):
+        for _ in range(Trainer.GRAPH_WARMUP + 2 if phase == 0 else 3):
+            images, targets = _batch(step, (2, 0, 3))
+            eager.step(images, targets)
+            graphed.step(images, targets)
+            step += 1
+        assert len(graphed._graphs) == 1
+        a, b = evaluate(ref_model), evaluate(graph_model)
+        tol = 2e-3 if amp is None else 5e-2
+        for x, y in zip(a, b):
+            torch.testing.assert_close(y, x, rtol=tol, atol=tol, msg=lambda s: f"validation {phase}: {s}")
+        if prev is not None:  # the second validation is NOT the first one again (lr 1e-3 moves the scores visibly)
+            assert float((a[1] - prev[1]).abs().max()) > 0 and float((b[1] - prev[1]).abs().max()) > 0
+        prev = b

@@ -234,3 +234,39 @@ def test_segmentation_confusion_metrics_hand_cases():
     # class 0: TP 2, FP 0 (pixel 6 was ignored), FN 1 -> 2/3; class 1: TP 2, FP 1, FN 0 -> 2/3; classes 2 (ignored), 3 (absent) out
     assert abs(r["mean_iou"] - 2 / 3) < 1e-12
     assert SegmentationConfusion(3).compute()["mean_iou"] != SegmentationConfusion(3).compute()["mean_iou"]  # NaN before any update
+
+
+def test_pad_targets_on_cpu_tensors():
+    """ObjectDetection._pad_targets is device-agnostic (round-3 advisor finding: it asked the CUDA runtime whether a stream
+    capture was running even for CPU targets, which raises on a box without a HIP device)."""
+    from sihl_amd.heads.object_detection import ObjectDetection
+    boxes = [torch.tensor([[1., 2., 3., 4.], [5., 6., 7., 8.]]), torch.zeros(0, 4), torch.tensor([[0., 0., 9., 9.]])]
+    classes = [torch.tensor([3, 1]), torch.zeros(0, dtype=torch.int64), torch.tensor([2])]
+    b, c, ok = ObjectDetection._pad_targets(boxes, classes, torch.device("cpu"))
+    assert b.shape == (3, 2, 4) and c.shape == (3, 2) and ok.shape == (3, 2)
+    assert ok.tolist() == [[True, True], [False, False], [True, False]]
+    assert torch.equal(b[0], boxes[0]) and torch.equal(b[2, 0], boxes[2][0])
+    assert b[1].tolist() == [[0, 0, 1, 1]] * 2 and c.tolist() == [[3, 1], [0, 0], [2, 0]]
+    b0, c0, ok0 = ObjectDetection._pad_targets([torch.zeros(0, 4)], [torch.zeros(0, dtype=torch.int64)], "cpu")
+    assert b0.shape == (1, 0, 4) and ok0.shape == (1, 0)
+
+
+def test_shipped_library_refuses_tuning_state():
+    """The ablation / tuning setters are live in `make TUNING=1` libraries only: the shipped one stores nothing (no
+    process-wide state that can invalidate results) and answers SIHL_EARG to any non-default request."""
+    import os
+    from sihl_amd import _C
+    if os.environ.get("SIHL_HIP_LIB"):
+        pytest.skip("a tuning build is loaded")
+    lib = _C.lib()
+    for name, default in (("sihl_conv2d_debug", 0), ("sihl_conv2d_nbuf_override", 0), ("sihl_conv2d_rules_off", 0),
+                          ("sihl_conv2d_krot", 200013), ("sihl_mlp_debug", 0), ("sihl_mlp_rows_debug", 0)):
+        assert getattr(lib, name)(default) == 0, name
+        assert getattr(lib, name)(default + 1) == -1, name
+
+
+def test_averager_without_trainable_parameters_does_not_raise():
+    from sihl_amd.train import GradientAverager
+    avg = GradientAverager([torch.zeros(3)], force=False)
+    avg.active, avg.buckets = True, []  # an active averager with nothing to average (all parameters frozen)
+    avg.finish()
