@@ -93,7 +93,7 @@ int sihl_conv2d_dgrad_add(const void* dout, const void* wt_t, void* din, const v
                           int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, int dtype, void* ws,
                           long ws_bytes, hipStream_t stream);
 int sihl_conv2d_splitk_enable(int on); /* tuning / test hook */
-int sihl_conv2d_small_enable(int on);  /* tuning / test hook: 0 = 3x3 convs of the small pyramid levels on the general kernel, not csrc/conv_small.hip */
+int sihl_conv2d_small_enable(int on);  /* test hook: kernel of the 3x3 convs on the small pyramid levels - 1 (default) csrc/conv_pyr.hip where its shapes allow, else csrc/conv_small.hip; 2 = conv_small.hip only; 0 = the general tile kernel */
 int sihl_conv2d_rules_off(int mask);   /* TUNING builds only: disable individual dispatch rules */
 int sihl_conv2d_krot(int n);           /* TUNING builds only: stage stride between neighbouring workgroups' K-loop starts (100000 * log2(group) + 1000 * min_stages + stride; default 200013 = groups of 4 workgroups share a start, stride 13; 0 = lockstep) */
 
@@ -211,6 +211,27 @@ int sihl_blur_fuse(const void* a, const void* b, const void* c, const float* wra
 int sihl_blur_fuse_bwd(const void* dout, const void* a, const void* b, const void* c, const float* wraw,
                        const float* a_scale, const float* a_shift, void* da, void* db, void* dc, float* dw_raw,
                        float* gacc, int N, int H, int W, int C, int dtype, hipStream_t stream);
+
+/* 3x3 / stride 1 / pad 1 conv of the pyramid's TOP levels with its fusion node folded into the loader (bf16; square maps of
+ * W = 16, 8 or 4; csrc/conv_pyr.hip).  One launch replaces [fusion kernel -> conv -> split-K finish] of a BiFPNLayer node
+ * (layers/bifpn.py:41-52: `up_convs[i](up_fusions[i]([upscalers[i](td[-1]), inputs[..]]))` and
+ * `down_convs[i](down_fusions[i]([downscalers[i](bu[-1]), inputs[i + 1], td[i + 1]]))`, conv blocks of
+ * layers/convblocks.py:37-87), bit-identical to those kernels run one after the other:
+ *   mode 0: out = epilogue(conv3x3(in))
+ *   mode 1: m = softmax(fw)_0 * bilinear_x2(a) + softmax(fw)_1 * b          a [N][W/2][W/2][Cin], b [N][W][W][Cin]; W = 8 or 4
+ *   mode 2: m = softmax(fw)_0 * (blur_s2(a) * a_scale + a_shift) + softmax(fw)_1 * b + softmax(fw)_2 * c
+ *           a [N][2W][2W][Cin] (reflect-padded binomial blur, stride 2: layers/pooling.py:7-26), b, c [N][W][W][Cin];
+ *           a_scale / a_shift optional (both or neither), as in sihl_blur_fuse; W = 8 or 4 only
+ *   modes 1, 2: out = epilogue(conv3x3(m)); `merged` (optional, [N][W][W][Cin]) receives m (the weight gradient needs it).
+ * wt [Cout][3][3][Cin]; Cin % 64 == 0, Cout % 32 == 0.  Epilogue as sihl_conv2d_fwd (bias -> [stats] -> pre-affine -> act ->
+ * [stats] -> post-affine); statistics rows: sihl_pyr_conv_stat_rows(N, W) of [2][Cout] fp32 (one per 128 pixels on 16x16
+ * maps, else one per tile: an 8x8 image / four 4x4 images), to be reduced by sihl_bn_finalize. */
+int sihl_pyr_conv_supported(int N, int W, int Cin, int Cout, int mode);
+int sihl_pyr_conv_stat_rows(int N, int W);
+int sihl_pyr_conv_fwd(const void* in, const void* wt, const float* bias, void* out, int N, int W, int Cin, int Cout, int act,
+                      const float* pre_scale, const float* pre_shift, const float* post_scale, const float* post_shift,
+                      int stats_mode, float* stats, long stats_bytes, int mode, const void* a, const void* b, const void* c,
+                      const float* fw, const float* a_scale, const float* a_shift, void* merged, hipStream_t stream);
 int sihl_fuse_sum(const void* x0, const void* x1, const void* x2, const float* wraw, void* out, long numel, int n,
                   int dtype, hipStream_t stream);
 int sihl_fuse_sum_bwd(const void* dout, const void* x0, const void* x1, const void* x2, const float* wraw, void* d0,

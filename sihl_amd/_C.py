@@ -79,6 +79,9 @@ SIGNATURES = {
     "sihl_fuse_sum": (I, [P, P, P, P, P, L, I, I, P]),
     "sihl_fuse_sum_bwd": (I, [P, P, P, P, P, P, P, P, P, P, L, I, I, P]),
     "sihl_blur_fuse": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "sihl_pyr_conv_supported": (I, [I, I, I, I, I]),
+    "sihl_pyr_conv_stat_rows": (I, [I, I]),
+    "sihl_pyr_conv_fwd": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, I, P, L, I, P, P, P, P, P, P, P, P]),
     "sihl_blur_fuse_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "sihl_layernorm_act": (I, [P, P, L, I, P, P, F, I, P, P, I, P]),
     "sihl_layernorm_bwd_waves": (I, [L]),

@@ -79,6 +79,19 @@ __device__ __forceinline__ float act_grad(float v, int act) {
   }
 }
 
+// The two BiFPN fusion nodes, element by element, with the rounding points spelled out (explicit fma / mul: hipcc contracts
+// a * b + c on its own, and differently from one kernel to the next).  elementwise.hip (stand-alone nodes) and conv_pyr.hip
+// (node inside the conv loader) both use these, so the two forms give the same bits.
+__device__ __forceinline__ float node_up2(float ly0, float ly1, float lx0, float lx1, float f00, float f01, float f10, float f11) {
+  const float t0 = __fmaf_rn(lx1, f01, __fmul_rn(lx0, f00));
+  const float t1 = __fmaf_rn(lx1, f11, __fmul_rn(lx0, f10));
+  return __fmaf_rn(ly1, t1, __fmul_rn(ly0, t0));
+}
+__device__ __forceinline__ float node_fuse2(float w0, float w1, float up, float b) { return __fmaf_rn(w1, b, __fmul_rn(w0, up)); }
+__device__ __forceinline__ float node_fuse3(float w0, float w1, float w2, float a, float b, float c) {
+  return __fmaf_rn(w2, c, __fmaf_rn(w1, b, __fmul_rn(w0, a)));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -60,8 +60,9 @@ long sihl_conv2d_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW
 // Tuning hook: switch individual dispatch rules off (bit 0: single-stage narrow tiles, bit 1: thin pointwise -> 128x128).
 int sihl_conv2d_rules_off(int mask) { SIHL_TUNING_SET(g_rules_off, mask); }
 
-// Tuning / test hook: 0 = the small pyramid levels' 3x3 convs take the general kernel instead of conv_small.hip.
-int sihl_conv2d_small_enable(int on) { sihl_small_set_enabled(on != 0); return 0; }
+// Test hook: kernel of the 3x3 convs on the small pyramid levels - 1 (default) = conv_pyr.hip where its shapes allow, else
+// conv_small.hip; 2 = conv_small.hip only; 0 = the general tile kernel.  All three stay parity-tested.
+int sihl_conv2d_small_enable(int on) { sihl_small_set_enabled(on != 0); sihl_pyr_set_mode(on); return 0; }
 
 // Tuning hook: 100000 * log2(group) + 1000 * min_stages + stride - the stage stride between the K-loop starts of
 // neighbouring GROUPS of workgroups (default 200013: groups of 4 share a start and with it their L2 fills, stride 13;

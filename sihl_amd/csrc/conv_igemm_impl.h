@@ -1065,6 +1065,7 @@ int dispatch(const ConvParams& p, hipStream_t stream) {
   const bool dma = !g_force_reg && in_bytes < (1L << 31) && wt_bytes < (1L << 31) && p.KH * p.KW <= 32;
   if constexpr (sizeof(T) == 2) {
     // 3x3 convs of the small pyramid levels: halo-resident input patch, split-K finished inside the launch (conv_small.hip)
+    if (dma && g_tile_override == 0 && !g_nbuf && sihl_pyr_eligible(p)) return sihl_pyr_launch(p, stream);
     if (dma && g_tile_override == 0 && !g_nbuf && sihl_small_eligible(p)) return sihl_small_launch(p, stream);
   }
   if (!dma) {

@@ -49,5 +49,9 @@ bool sihl_small_eligible(const ConvParams& p);
 int sihl_small_launch(const ConvParams& p, hipStream_t stream);
 void sihl_small_set_enabled(bool on);
 long sihl_small_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil);
+// conv_pyr.hip: image-major 3x3 kernel of the pyramid's top levels (bf16), preferred over conv_small.hip where eligible
+bool sihl_pyr_eligible(const ConvParams& p);
+int sihl_pyr_launch(const ConvParams& p, hipStream_t stream);
+void sihl_pyr_set_mode(int mode);
 // conv_igemm_bf16.hip: the finishing launch of a split-K conv (sums the fp32 slices, runs the epilogue), for conv_small.hip
 int sihl_conv_splitk_finish_bf16(const ConvParams& p, hipStream_t stream);

@@ -289,8 +289,8 @@ __global__ void fuse_up2_kernel(const T* __restrict__ a, const T* __restrict__ b
   if (b) ldv(b + i, o);
 #pragma unroll
   for (int e = 0; e < V; ++e) {
-    const float up = ly.l0 * (lx.l0 * f00[e] + lx.l1 * f01[e]) + ly.l1 * (lx.l0 * f10[e] + lx.l1 * f11[e]);
-    o[e] = b ? w[0] * up + w[1] * o[e] : up;
+    const float up = node_up2(ly.l0, ly.l1, lx.l0, lx.l1, f00[e], f01[e], f10[e], f11[e]);
+    o[e] = b ? node_fuse2(w[0], w[1], up, o[e]) : up;
   }
   stv(out + i, o);
 }
@@ -558,7 +558,7 @@ __global__ void blur_fuse_kernel(const T* __restrict__ a, const T* __restrict__ 
       ldv(ar + xs[dx], f);
       const float k = k1[dy] * k1[dx];
 #pragma unroll
-      for (int e = 0; e < V; ++e) acc[e] += k * f[e];
+      for (int e = 0; e < V; ++e) acc[e] = __fmaf_rn(k, f[e], acc[e]);
     }
   }
   if (a_scale) {
@@ -566,7 +566,7 @@ __global__ void blur_fuse_kernel(const T* __restrict__ a, const T* __restrict__ 
     ldparam<V>(a_scale, cv * V, sc, 1.f);
     ldparam<V>(a_shift, cv * V, sf, 0.f);
 #pragma unroll
-    for (int e = 0; e < V; ++e) acc[e] = acc[e] * sc[e] + sf[e];
+    for (int e = 0; e < V; ++e) acc[e] = __fmaf_rn(acc[e], sc[e], sf[e]);
   }
   const long i = ((long)row * Wo + ox) * C + cv * V;
   if (b) {
@@ -574,7 +574,7 @@ __global__ void blur_fuse_kernel(const T* __restrict__ a, const T* __restrict__ 
     ldv(b + i, fb);
     ldv(c + i, fc);
 #pragma unroll
-    for (int e = 0; e < V; ++e) acc[e] = w[0] * acc[e] + w[1] * fb[e] + w[2] * fc[e];
+    for (int e = 0; e < V; ++e) acc[e] = node_fuse3(w[0], w[1], w[2], acc[e], fb[e], fc[e]);
   }
   stv(out + i, acc);
 }

@@ -80,6 +80,23 @@ class _ConvBlock(nn.Sequential):
             y = ops.conv_block(x, weight, bias, None, None, None, None, stride=sh, pad=ph, dil=dh, act=self.act)
         return y if y.shape[-1] == cout else y[..., :cout]
 
+    def forward_fused_node(self, fuse, defer=None) -> Optional[Tensor]:
+        """This block applied to a BiFPN fusion node, node and conv in ONE launch (ops.fused_node_conv_block; fuse = ("up2", a,
+        b, wraw) or ("blur", a, b, c, wraw, a_affine)).  None when the block or the shapes are outside that kernel: the caller
+        then computes the node itself and calls forward_nhwc."""
+        if self.order != "act_norm" or self.act not in (None, "relu"):
+            return None
+        conv, bn = self._parts()
+        if (bn is None or conv.groups != 1 or conv.padding_mode != "zeros" or conv.kernel_size != (3, 3) or conv.stride != (1, 1)
+                or conv.padding != (1, 1) or conv.dilation != (1, 1) or bn.momentum is None or not bn.track_running_stats
+                or not bn.affine or any(isinstance(m, (nn.GroupNorm, nn.Softplus, nn.Softmax)) for m in self)):
+            return None
+        y = ops.fused_node_conv_block(fuse, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                      act=self.act, training=self.training, eps=bn.eps, momentum=bn.momentum, defer=defer)
+        if y is not None and self.training:
+            ops.bump_counter(bn.num_batches_tracked)
+        return y
+
     def forward_nhwc_into(self, x: Tensor, out: Tensor, out_image_stride: int) -> bool:
         """Inference only: write this block's output for image n at ``out`` + n * out_image_stride elements (a slice of a
         larger buffer).  Returns False - and writes nothing - when the block is not the plain case the one-launch path

@@ -69,16 +69,22 @@ class BiFPNLayer(nn.Module):
         down = {top: feats[top]}
         for k in range(top):
             lvl = top - 1 - k
-            merged = ops.fuse_up2(down[lvl + 1], feats[lvl], self.up_fusions[k].weights)
-            down[lvl] = self.up_convs[k].forward_nhwc(merged)
+            # node + conv block as one launch on the small maps (csrc/conv_pyr.hip), else fusion kernel, then conv
+            y = self.up_convs[k].forward_fused_node(("up2", down[lvl + 1], feats[lvl], self.up_fusions[k].weights))
+            if y is None:
+                y = self.up_convs[k].forward_nhwc(ops.fuse_up2(down[lvl + 1], feats[lvl], self.up_fusions[k].weights))
+            down[lvl] = y
         # ascend: module k produces level k+1 from (blurred conv of level k, the input, the top-down map)
         out = [down[0]]
         for k in range(top):
             # conv block of the downscaler; its blur - and in training its BatchNorm affine - is fused into the merge below
             affine = ops.DeferredAffine()
             pre = self.downscalers[k][0].forward_nhwc(out[k], defer=affine)
-            merged = ops.blur_fuse(pre, feats[k + 1], down[k + 1], self.down_fusions[k].weights, a_affine=affine)
-            out.append(self.down_convs[k].forward_nhwc(merged))
+            w3 = self.down_fusions[k].weights
+            y = self.down_convs[k].forward_fused_node(("blur", pre, feats[k + 1], down[k + 1], w3, affine))
+            if y is None:
+                y = self.down_convs[k].forward_nhwc(ops.blur_fuse(pre, feats[k + 1], down[k + 1], w3, a_affine=affine))
+            out.append(y)
         return out
 
     def forward(self, inputs: Sequence[Tensor]) -> List[Tensor]:

@@ -377,6 +377,48 @@ def conv2d_raw(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, stride: int 
     return out, stats
 
 
+def pyr_conv_supported(N: int, W: int, Cin: int, Cout: int, mode: int, dtype) -> bool:
+    return dtype == torch.bfloat16 and bool(_sized("sihl_pyr_conv_supported", N, W, Cin, Cout, mode))
+
+
+def pyr_conv_raw(w: Tensor, x: Optional[Tensor] = None, fuse=None, bias: Optional[Tensor] = None, act: Optional[str] = None,
+                 pre: Optional[Tuple[Tensor, Tensor]] = None, post: Optional[Tuple[Tensor, Tensor]] = None,
+                 stats_mode: int = 0, want_merged: bool = False):
+    """3x3 / pad 1 conv of a small square map (16, 8 or 4 wide, bf16) with its fusion node folded into the loader
+    (sihl_pyr_conv_fwd, csrc/conv_pyr.hip).  Input: ``x`` (N, W, W, Cin), or ``fuse`` =
+    ("up2", a, b, wraw)                  -> softmax(wraw)_0 * bilinear_x2(a) + softmax(wraw)_1 * b,  or
+    ("blur", a, b, c, wraw, a_affine)    -> softmax(wraw)_0 * (blur_s2(a) * scale + shift) + .._1 * b + .._2 * c
+    (a_affine = (scale, shift) or None).  Returns (y, stats, merged): stats fp32 [rows][2][Cout] when stats_mode != 0,
+    merged = the conv's input when want_merged (training: the weight gradient reads it)."""
+    Cout, KH, KW, Cin = w.shape
+    assert KH == 3 and KW == 3
+    a = b = c = wraw = a_scale = a_shift = None
+    if fuse is None:
+        mode, ref = 0, x
+    elif fuse[0] == "up2":
+        mode, (a, b, wraw), ref = 1, fuse[1:4], fuse[2]
+    else:
+        mode, (a, b, c, wraw), ref = 2, fuse[1:5], fuse[2]
+        if len(fuse) > 5 and fuse[5] is not None:
+            a_scale, a_shift = fuse[5]
+    _require_gpu(ref)
+    N, W = ref.shape[0], ref.shape[2]
+    if ref.shape[1] != W or ref.shape[3] != Cin or not pyr_conv_supported(N, W, Cin, Cout, mode, ref.dtype):
+        raise ValueError(f"pyr_conv_raw: unsupported problem {tuple(ref.shape)} -> {Cout}, mode {mode}, {ref.dtype}")
+    out = torch.empty((N, W, W, Cout), dtype=ref.dtype, device=ref.device)
+    merged = torch.empty_like(ref) if (want_merged and mode != 0) else None
+    stats, stats_bytes = None, 0
+    if stats_mode:
+        stats = torch.empty((_sized("sihl_pyr_conv_stat_rows", N, W), 2, Cout), dtype=torch.float32, device=ref.device)
+        stats_bytes = stats.numel() * 4
+    rc = _C.lib().sihl_pyr_conv_fwd(
+        _p(x), _p(w), _p(bias), _p(out), N, W, Cin, Cout, ACT[act],
+        _p(pre[0]) if pre else None, _p(pre[1]) if pre else None, _p(post[0]) if post else None, _p(post[1]) if post else None,
+        stats_mode, _p(stats), stats_bytes, mode, _p(a), _p(b), _p(c), _p(wraw), _p(a_scale), _p(a_shift), _p(merged), _stream())
+    check(rc, "sihl_pyr_conv_fwd")
+    return out, stats, (x if mode == 0 else merged)
+
+
 def conv2d_wgrad_raw(x: Tensor, dout: Tensor, KH: int, KW: int, stride: int, pad: int, dil: int) -> Tensor:
     """Returns fp32 dW [Cout][KH][KW][Cin]."""
     N, H, W, Cin = x.shape
@@ -667,7 +709,9 @@ class ConvBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, cfg, residual=None, hand_over=None,
-                take_over=None, dx_to=None, defer=None):
+                take_over=None, dx_to=None, defer=None, precomputed=None):
+        # precomputed = (s, stats): the conv pass has already run (fused_node_conv_block: the launch that computed the
+        # fusion node `x` inside its loader); everything else - BatchNorm, the saved tensors, the backward - is this block's
         stride, pad, dil, act, order, has_norm, training, eps, momentum, need_grad = cfg
         xd = x.detach()
         ctx.has_res = residual is not None
@@ -700,8 +744,11 @@ class ConvBlockFn(torch.autograd.Function):
         ctx.mode = mode
         if training:
             # one conv pass producing the pre-norm tensor + per-channel partial sums
-            s, stats = conv2d_raw(xd, w, bias, stride, pad, dil, act=act if mode == 0 else None,
-                                  stats_mode=2 if mode == 0 else 1)
+            if precomputed is not None:
+                s, stats = precomputed
+            else:
+                s, stats = conv2d_raw(xd, w, bias, stride, pad, dil, act=act if mode == 0 else None,
+                                      stats_mode=2 if mode == 0 else 1)
             count = s.numel() // s.shape[-1]
             mean, rstd, scale, shift = bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean,
                                                    running_var)
@@ -811,7 +858,7 @@ class ConvBlockFn(torch.autograd.Function):
                                            _stream())
             check(rc, "sihl_conv2d_dgrad")
         _guard_shared_parameters(ctx.pkeys)
-        return dx, dw, dbias, dgamma, dbeta, None, None, None, dres, None, None, None, None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, dres, None, None, None, None, None
 
 
 DEFER_BN_AFFINE = os.environ.get("SIHL_DEFER_BN_AFFINE", "1") != "0"  # A/B and test switch: False = every conv block applies its BatchNorm affine itself
@@ -903,17 +950,77 @@ def conv_block(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, *, 
     return add_relu(ConvBlockFn.apply(x_nhwc, weight, bias, gamma, beta, running_mean, running_var, cfg), residual)
 
 
+# Opt-in (tests, A/B): the fusion node inside the conv's loader.  Off by default: every one of a map's 8 output-slice
+# workgroups recomputes the whole node, and on the GPU the one-launch form only ties with [fusion kernel -> conv] on the
+# top-down nodes (P6 9.3 -> 8.8 us, P7 8.1 -> 8.3) and loses on the bottom-up ones (P6 10.8 -> 11.3, P7 8.8 -> 10.7;
+# profiles/r04_pyr_probe.txt) - it saves host launches, not GPU time.
+FUSE_NODE_CONV = os.environ.get("SIHL_FUSE_NODE_CONV", "0") != "0"
+
+
+def fused_node_conv_block(fuse, weight, bias, gamma, beta, running_mean, running_var, *, act, training, eps=1e-5,
+                          momentum=0.1, defer=None):
+    """A BiFPN fusion node and the conv -> act -> BatchNorm block behind it as ONE launch (conv_pyr.hip: the node is computed
+    inside the conv's loader; reference layers/bifpn.py:41-52).  fuse = ("up2", a, b, wraw) or ("blur", a, b, c, wraw,
+    a_affine) with a_affine a DeferredAffine or None.  Returns the block's output, or None when the problem is outside
+    the kernel's shapes (the caller then runs the node and the block separately - same values: the fused launch is
+    bit-identical to that sequence).
+
+    Training: the launch also stores the node's value (the weight gradient reads it) and the autograd graph is the usual
+    one - FuseUp2Fn / BlurFuseFn feeding ConvBlockFn, each told that its forward has already been computed."""
+    kind, a, b = fuse[0], fuse[1], fuse[2]
+    c = fuse[3] if kind == "blur" else None
+    wraw = fuse[3] if kind == "up2" else fuse[4]
+    a_affine = fuse[5] if kind == "blur" and len(fuse) > 5 else None
+    mode = 1 if kind == "up2" else 2
+    N, W, Cin = b.shape[0], b.shape[2], b.shape[3]
+    Cout = weight.shape[0]
+    if (not FUSE_NODE_CONV or not b.is_cuda or b.shape[1] != W or tuple(weight.shape[2:]) != (3, 3) or weight.shape[1] != Cin
+            or not pyr_conv_supported(N, W, Cin, Cout, mode, b.dtype) or a.dtype != b.dtype
+            or tuple(a.shape) != ((N, W // 2, W // 2, Cin) if mode == 1 else (N, 2 * W, 2 * W, Cin))
+            or (c is not None and (c.shape != b.shape or c.dtype != b.dtype))):
+        return None
+    tensors = (a, b, c, wraw, weight, bias, gamma, beta)
+    need_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+    if not training and need_grad:
+        return None  # eval-mode statistics with autograd: the general path keeps what the backward needs
+    prep = prepared(weight, b.dtype)
+    w = prep.w if prep is not None else weight_khwc(weight, b.dtype)
+    aff = None
+    if a_affine is not None and a_affine.scale is not None:
+        aff = (a_affine.scale, a_affine.shift)
+    wr = wraw.detach().float().contiguous()
+    ad, bd = a.detach().contiguous(), b.detach().contiguous()
+    raw = ("up2", ad, bd, wr) if mode == 1 else ("blur", ad, bd, c.detach().contiguous(), wr, aff)
+    if not training:
+        scale, shift = bn_eval_affine(gamma, beta, running_mean, running_var, eps)
+        return pyr_conv_raw(w, fuse=raw, bias=bias, act=act, post=(scale, shift))[0]
+    s, stats, merged = pyr_conv_raw(w, fuse=raw, bias=bias, act=act, stats_mode=2, want_merged=True)
+    if mode == 1:
+        m = FuseUp2Fn.apply(a, b, wraw, merged)
+    else:
+        m = BlurFuseFn.apply(a, b, c, wraw, aff[0] if aff else None, aff[1] if aff else None, merged)
+    cfg = (1, 1, 1, act, "act_norm", True, True, eps, momentum, need_grad)
+    if defer is not None and not DEFER_BN_AFFINE:
+        defer = None
+    return ConvBlockFn.apply(m, weight, bias, gamma, beta, running_mean, running_var, cfg, None, None, None, None, defer,
+                             (s, stats))
+
+
 # ----------------------------------------------------------------------------- fusion nodes
 class FuseUp2Fn(torch.autograd.Function):
     """out = softmax(w)[0] * bilinear_x2(a) + softmax(w)[1] * b   (NHWC)."""
 
     @staticmethod
-    def forward(ctx, a, b, wraw):
+    def forward(ctx, a, b, wraw, precomputed=None):
+        # precomputed: the node's value, already produced by the conv launch that consumes it (fused_node_conv_block)
         a, b, wr = a.detach().contiguous(), b.detach().contiguous(), wraw.detach().float().contiguous()
         N, H, W, C = b.shape
-        out = torch.empty_like(b)
-        rc = _C.lib().sihl_fuse_up2(_p(a), _p(b), _p(wr), _p(out), N, H, W, C, _dt(b), _stream())
-        check(rc, "sihl_fuse_up2")
+        if precomputed is not None:
+            out = precomputed.view_as(precomputed)
+        else:
+            out = torch.empty_like(b)
+            rc = _C.lib().sihl_fuse_up2(_p(a), _p(b), _p(wr), _p(out), N, H, W, C, _dt(b), _stream())
+            check(rc, "sihl_fuse_up2")
         ctx.save_for_backward(a, b, wr)
         return out
 
@@ -930,7 +1037,7 @@ class FuseUp2Fn(torch.autograd.Function):
         rc = _C.lib().sihl_fuse_up2_bwd(_p(dout), _p(a), _p(b), _p(wr), _p(da), _p(db), _p(dw), _p(gacc), N, H, W, C,
                                         _dt(b), _stream())
         check(rc, "sihl_fuse_up2_bwd")
-        return da, db, dw
+        return da, db, dw, None
 
 
 class BlurFuseFn(torch.autograd.Function):
@@ -939,7 +1046,7 @@ class BlurFuseFn(torch.autograd.Function):
     gradient returned for it is that of ``a * scale + shift``, which is what the block's backward expects."""
 
     @staticmethod
-    def forward(ctx, a, b, c, wraw, a_scale=None, a_shift=None):
+    def forward(ctx, a, b, c, wraw, a_scale=None, a_shift=None, precomputed=None):
         a = a.detach().contiguous()
         N, H, W, C = a.shape
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
@@ -948,10 +1055,13 @@ class BlurFuseFn(torch.autograd.Function):
             b, c, wr = b.detach().contiguous(), c.detach().contiguous(), wraw.detach().float().contiguous()
         else:
             wr = None
-        out = torch.empty((N, Ho, Wo, C), dtype=a.dtype, device=a.device)
-        rc = _C.lib().sihl_blur_fuse(_p(a), _p(b), _p(c), _p(wr), _p(a_scale), _p(a_shift), _p(out), N, H, W, C, _dt(a),
-                                     _stream())
-        check(rc, "sihl_blur_fuse")
+        if precomputed is not None:  # the node's value, already produced by the conv launch that consumes it
+            out = precomputed.view_as(precomputed)
+        else:
+            out = torch.empty((N, Ho, Wo, C), dtype=a.dtype, device=a.device)
+            rc = _C.lib().sihl_blur_fuse(_p(a), _p(b), _p(c), _p(wr), _p(a_scale), _p(a_shift), _p(out), N, H, W, C, _dt(a),
+                                         _stream())
+            check(rc, "sihl_blur_fuse")
         ctx.fused = fused
         ctx.save_for_backward(a, b, c, wr, a_scale, a_shift)
         return out
@@ -971,7 +1081,7 @@ class BlurFuseFn(torch.autograd.Function):
         rc = _C.lib().sihl_blur_fuse_bwd(_p(dout), _p(a), _p(b), _p(c), _p(wr), _p(a_scale), _p(a_shift), _p(da), _p(db),
                                          _p(dc), _p(dw), _p(gacc), N, H, W, C, _dt(a), _stream())
         check(rc, "sihl_blur_fuse_bwd")
-        return da, db, dc, dw, None, None
+        return da, db, dc, dw, None, None, None
 
 
 class Up2Fn(torch.autograd.Function):

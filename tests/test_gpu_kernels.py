@@ -612,11 +612,14 @@ def test_conv_splitk_matches_single_pass(shape, dtype, tol):
     torch.testing.assert_close(outs[1][1].sum(0), outs[0][1].sum(0), rtol=1e-3, atol=1e-3 * float(outs[0][1].abs().max()))
 
 
+@pytest.mark.parametrize("kernel", [1, 2])
 @pytest.mark.parametrize("mode", ["eval", "train_act_norm", "train_norm_act", "bias_silu", "plain"])
 @pytest.mark.parametrize("shape", [(32, 16, 256, 256), (32, 8, 256, 256), (32, 4, 256, 256), (3, 4, 256, 256), (5, 8, 64, 128),
                                    (2, 16, 128, 64), (1, 16, 192, 64), (9, 4, 512, 64)])
-def test_conv_small_levels(shape, mode):
-    """conv_small.hip - the 3x3 convs of the small pyramid levels (16x16 / 8x8 / 4x4 maps; halo-resident input patch, weight
+def test_conv_small_levels(shape, mode, kernel):
+    """kernel 1: conv_pyr.hip through the generic conv entry (image-major tiles, round 4; it takes the launch where its
+    statistics rows are the generic ones - 16x16 maps, or no statistics - and leaves the rest to conv_small.hip); kernel 2:
+    conv_small.hip - the 3x3 convs of the small pyramid levels (16x16 / 8x8 / 4x4 maps; halo-resident input patch, weight
     ring per kernel row, split-K over the channel chunks with the general kernel's finishing launch) -
     against the general kernel on the same operands (same bf16 operands, fp32 sums in another order) and an fp32 PyTorch
     conv, for every epilogue the conv blocks use; ragged last tiles (3 maps of 4x4 = 48 of 128 pixels), one to eight
@@ -637,12 +640,18 @@ def test_conv_small_levels(shape, mode):
     try:
         lib.sihl_conv2d_small_enable(0)
         y0, s0 = run()
+        lib.sihl_conv2d_small_enable(kernel)
+        lib.sihl_profile_enable(1)
+        y1, s1 = run()
+        torch.cuda.synchronize()
+        lib.sihl_profile_enable(0)
+        for _ in range(30):
+            y2, s2 = run()
+            assert torch.equal(y2.view(torch.int16), y1.view(torch.int16))
+            if s1 is not None:
+                assert torch.equal(s2, s1)
     finally:
         lib.sihl_conv2d_small_enable(1)
-    lib.sihl_profile_enable(1)
-    y1, s1 = run()
-    torch.cuda.synchronize()
-    lib.sihl_profile_enable(0)
     ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias_arg, padding=1).permute(0, 2, 3, 1)
     pre = ref
     if "pre" in kw:
@@ -662,11 +671,71 @@ def test_conv_small_levels(shape, mode):
         torch.testing.assert_close(s1[:, 0], src.sum(1), rtol=1e-3, atol=1e-3 * float(src.abs().sum(1).max()))
         torch.testing.assert_close(s1[:, 1], (src * src).sum(1), rtol=1e-3, atol=1e-3 * float((src * src).sum(1).max()))
         torch.testing.assert_close(s1, s0, rtol=1e-4, atol=1e-4 * float(s0.abs().max()))
-    for _ in range(30):
-        y2, s2 = run()
-        assert torch.equal(y2.view(torch.int16), y1.view(torch.int16))
-        if s1 is not None:
-            assert torch.equal(s2, s1)
+
+
+@pytest.mark.parametrize("train", [False, True])
+@pytest.mark.parametrize("shape", [(32, 16, 256, 256), (32, 8, 256, 256), (32, 4, 256, 256), (3, 4, 256, 256), (5, 8, 64, 128),
+                                   (2, 16, 128, 64), (1, 16, 192, 96), (9, 4, 512, 32)])
+def test_pyr_conv_fused_producers(shape, train):
+    """sihl_pyr_conv_fwd (conv_pyr.hip): the BiFPN's top-level nodes as ONE launch each - [bilinear x2 + 2-way fusion -> 3x3
+    conv block] and [blur-pool + 3-way fusion (+ deferred BatchNorm affine) -> 3x3 conv block] - must be BIT-IDENTICAL to the
+    stand-alone fusion kernel followed by the same conv kernel on its output (same fp32 arithmetic, same bf16 rounding of the
+    merged tensor), which in turn is held to an fp32 PyTorch statement of the node; plus the merged tensor the weight
+    gradient needs, the statistics rows (their own row count) against sums of the output, ragged last tiles (3 and 9 maps
+    of 4x4) and run-to-run bit-identity."""
+    from sihl_amd import _C, ops
+    N, W, Cin, Cout = shape
+    g = torch.Generator(device="cuda").manual_seed(N * 1000 + W * 10 + Cin + int(train))
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)  # noqa: E731
+    w = (rnd(Cout, 3, 3, Cin) * (9 * Cin) ** -0.5).bfloat16()
+    sc, sh = torch.rand(Cout, device="cuda", generator=g) + 0.5, rnd(Cout)
+    kw = dict(act="relu", stats_mode=2) if train else dict(act="relu", post=(sc, sh))
+    lo, hi, skip, td = rnd(N, W // 2, W // 2, Cin).bfloat16(), rnd(N, 2 * W, 2 * W, Cin).bfloat16(), rnd(N, W, W, Cin).bfloat16(), rnd(N, W, W, Cin).bfloat16()
+    w2, w3 = rnd(2), rnd(3)
+    asc, ash = torch.rand(Cin, device="cuda", generator=g) + 0.5, rnd(Cin)
+    cases = []
+    if W == 16:  # no fused producer on 16x16 maps (measured slower than the stand-alone node): the plain mode only
+        assert not ops.pyr_conv_supported(N, W, Cin, Cout, 1, torch.bfloat16)
+        y0, s0 = ops.conv2d_raw(skip, w, None, 1, 1, 1, **kw)  # generic entry: the same kernel, generic statistics rows
+        y1, s1, _ = ops.pyr_conv_raw(w, x=skip, **kw)
+        if Cout % 64 == 0:  # (else the generic entry runs the general tile kernel: compared with the fp32 reference below)
+            assert torch.equal(y1.view(torch.int16), y0.view(torch.int16)) and (s0 is None or torch.equal(s1, s0))
+        ref = torch.relu(F.conv2d(skip.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), None, padding=1)).permute(0, 2, 3, 1)
+        if train:
+            torch.testing.assert_close(s1[:, 0], ref.reshape(-1, 128, Cout).sum(1), rtol=2e-3, atol=2e-3 * float(ref.reshape(-1, 128, Cout).sum(1).abs().max()))
+        else:
+            ref = ref * sc + sh
+        torch.testing.assert_close(y1.float(), ref, rtol=2e-2, atol=2e-2 * float(ref.abs().max()))
+    else:
+        cases.append(("up2", ("up2", lo, skip, w2), lambda: ops.fuse_up2(lo, skip, w2)))
+        cases.append(("blur", ("blur", hi, skip, td, w3, None), lambda: ops.blur_fuse(hi, skip, td, w3)))
+        aff = ops.DeferredAffine()
+        aff.scale, aff.shift = asc, ash
+        cases.append(("blur+affine", ("blur", hi, skip, td, w3, (asc, ash)), lambda: ops.blur_fuse(hi, skip, td, w3, a_affine=aff)))
+    for name, fuse, standalone in cases:
+        with torch.no_grad():
+            m_ref = standalone()
+        y0, s0, _ = ops.pyr_conv_raw(w, x=m_ref, **kw)
+        y1, s1, m1 = ops.pyr_conv_raw(w, fuse=fuse, want_merged=True, **kw)
+        assert torch.equal(m1.view(torch.int16), m_ref.view(torch.int16)), name
+        assert torch.equal(y1.view(torch.int16), y0.view(torch.int16)), name
+        ref = torch.relu(F.conv2d(m_ref.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), None, padding=1)).permute(0, 2, 3, 1)
+        if train:
+            assert torch.equal(s1, s0), name
+            rows = _C.lib().sihl_pyr_conv_stat_rows(N, W)
+            assert s1.shape == (rows, 2, Cout)
+            torch.testing.assert_close(s1[:, 0].sum(0), ref.reshape(-1, Cout).sum(0), rtol=2e-3, atol=2e-3 * float(ref.abs().sum((0, 1, 2)).max()))
+            torch.testing.assert_close(s1[:, 1].sum(0), (ref * ref).reshape(-1, Cout).sum(0), rtol=2e-3, atol=2e-3 * float((ref * ref).sum((0, 1, 2)).max()))
+            if W == 16:  # generic rows: one per 128 pixels
+                torch.testing.assert_close(s1[:, 0], ref.reshape(-1, 128, Cout).sum(1), rtol=2e-3, atol=2e-3 * float(ref.reshape(-1, 128, Cout).sum(1).abs().max()))
+        else:
+            ref = ref * sc + sh
+        torch.testing.assert_close(y1.float(), ref, rtol=2e-2, atol=2e-2 * float(ref.abs().max()), msg=lambda s: f"{name}: {s}")
+        for _ in range(10):
+            y2, s2, _ = ops.pyr_conv_raw(w, fuse=fuse, **kw)
+            assert torch.equal(y2.view(torch.int16), y1.view(torch.int16)), name
+            if train:
+                assert torch.equal(s2, s1), name
 
 
 @pytest.mark.parametrize("dtype,rtol,atol", DTYPES)
@@ -906,3 +975,48 @@ def test_bn_act_train_matches_batchnorm2d(shape, dtype, tol):
     torch.testing.assert_close(bn.running_mean, ref_bn.running_mean, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(bn.running_var, ref_bn.running_var, rtol=1e-4, atol=1e-5)
     assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_bifpn_fused_nodes_match_separate_launches(train):
+    """BiFPN at 512^2 (P5-P7 = 16x16, 8x8, 4x4 maps) in bf16 with the opt-in one-launch [fusion node + conv block] path
+    (ops.FUSE_NODE_CONV, conv_pyr.hip modes 1 / 2) against the default [fusion kernel -> conv]: the same bits in the outputs
+    and - training mode - the same bits in every input and parameter gradient and running statistic (the forward values are
+    bit-identical by construction and the backward runs the same kernels on them)."""
+    import copy
+
+    import sihl_amd
+    from sihl_amd import ops
+    chans = [3, 8, 16, 64, 128, 64]
+    torch.manual_seed(3)
+    neck = sihl_amd.layers.BiFPN(chans, 64, 3, 7, num_layers=2).cuda()
+    neck.train(train)
+    twin = copy.deepcopy(neck)
+    g = torch.Generator().manual_seed(4)
+    levels = [torch.zeros(2, 3, 512, 512)] + [torch.randn(2, c, 512 // 2 ** l, 512 // 2 ** l, generator=g) for l, c in enumerate(chans) if l > 0]
+
+    def run(model, fused):
+        lv = [t.cuda().bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(train and i >= 3) for i, t in enumerate(levels)]
+        old = ops.FUSE_NODE_CONV
+        ops.FUSE_NODE_CONV = fused
+        try:
+            with torch.set_grad_enabled(train):
+                out = model(lv)[3:]
+                if train:
+                    loss = sum((o.float() ** 2).mean() * (i + 1) for i, o in enumerate(out))
+                    loss.backward()
+        finally:
+            ops.FUSE_NODE_CONV = old
+        return [o.detach() for o in out], [t.grad for t in lv[3:]]
+
+    out_a, gin_a = run(neck, False)
+    out_b, gin_b = run(twin, True)
+    for a, b in zip(out_a, out_b):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    if train:
+        for a, b in zip(gin_a, gin_b):
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+        for (n, pa), pb in zip(neck.named_parameters(), twin.parameters()):
+            assert pa.grad is not None and torch.equal(pa.grad, pb.grad), n
+        for (n, ba), bb in zip(neck.named_buffers(), twin.buffers()):
+            assert torch.equal(ba, bb), n
