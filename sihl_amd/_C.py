@@ -45,6 +45,7 @@ SIGNATURES = {
     "sihl_conv2d_dgrad_add": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, L, P]),
     "sihl_conv2d_splitk_enable": (I, [I]),
     "sihl_conv2d_small_enable": (I, [I]),
+    "sihl_conv2d_small_mode": (I, []),
     "sihl_conv2d_rules_off": (I, [I]),
     "sihl_conv2d_krot": (I, [I]),
     "sihl_conv2d_wgrad_force_register_staging": (I, [I]),

@@ -63,6 +63,7 @@ int sihl_conv2d_rules_off(int mask) { SIHL_TUNING_SET(g_rules_off, mask); }
 // Test hook: kernel of the 3x3 convs on the small pyramid levels - 1 (default) = conv_pyr.hip where its shapes allow, else
 // conv_small.hip; 2 = conv_small.hip only; 0 = the general tile kernel.  All three stay parity-tested.
 int sihl_conv2d_small_enable(int on) { sihl_small_set_enabled(on != 0); sihl_pyr_set_mode(on); return 0; }
+int sihl_conv2d_small_mode(void) { return sihl_pyr_get_mode(); }
 
 // Tuning hook: 100000 * log2(group) + 1000 * min_stages + stride - the stage stride between the K-loop starts of
 // neighbouring GROUPS of workgroups (default 200013: groups of 4 share a start and with it their L2 fills, stride 13;

@@ -53,5 +53,6 @@ long sihl_small_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW,
 bool sihl_pyr_eligible(const ConvParams& p);
 int sihl_pyr_launch(const ConvParams& p, hipStream_t stream);
 void sihl_pyr_set_mode(int mode);
+int sihl_pyr_get_mode();
 // conv_igemm_bf16.hip: the finishing launch of a split-K conv (sums the fp32 slices, runs the epilogue), for conv_small.hip
 int sihl_conv_splitk_finish_bf16(const ConvParams& p, hipStream_t stream);

@@ -356,6 +356,12 @@ def conv2d_raw(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, stride: int 
     _require_gpu(x)
     N, H, W, Cin = x.shape
     Cout, KH, KW, _ = w.shape
+    if (stats_mode and out is None and W <= 8 and H == W and KH == 3 and KW == 3 and stride == 1 and pad == 1 and dil == 1
+            and pyr_conv_supported(N, W, Cin, Cout, 0, x.dtype) and _C.lib().sihl_conv2d_small_mode() == 1):
+        # 8x8 / 4x4 maps with BatchNorm statistics: conv_pyr.hip writes one partial row per TILE (an 8x8 image, four 4x4
+        # images) instead of the generic one per 128 pixels, so it is reached through its own entry; sihl_bn_finalize takes
+        # any number of rows
+        return pyr_conv_raw(w, x=x, bias=bias, act=act, pre=pre, post=post, stats_mode=stats_mode)[:2]
     Ho = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
     Wo = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
     if out is None:
@@ -1029,7 +1035,7 @@ class FuseUp2Fn(torch.autograd.Function):
         a, b, wr = ctx.saved_tensors
         dout = dout.contiguous()
         N, H, W, C = b.shape
-        need_a, need_b, need_w = ctx.needs_input_grad
+        need_a, need_b, need_w = ctx.needs_input_grad[:3]
         da = torch.empty_like(a) if need_a else None
         db = torch.empty_like(b) if need_b else None
         dw = torch.empty(2, dtype=torch.float32, device=b.device) if need_w else None

@@ -664,7 +664,16 @@ def test_conv_small_levels(shape, mode, kernel):
     torch.testing.assert_close(y1.float(), ref, rtol=2e-2, atol=2e-2 * scale)
     torch.testing.assert_close(y1.float(), y0.float(), rtol=1e-2, atol=1e-2 * scale)  # one bf16 ulp where the fp32 sums differ
     assert float((y1.float() - y0.float()).abs().mean()) < 1e-3 * scale
-    if kw.get("stats_mode"):
+    if kw.get("stats_mode") and kernel == 1 and W < 16 and lib.sihl_pyr_conv_supported(N, W, Cin, Cout, 0):
+        # conv_pyr.hip's own rows: one per tile (an 8x8 image / four 4x4 images)
+        per = 64
+        rows = lib.sihl_pyr_conv_stat_rows(N, W)
+        assert s1.shape == (rows, 2, Cout)
+        src = F.pad(stat_src.reshape(-1, Cout), (0, 0, 0, rows * per - N * W * W)).reshape(rows, per, Cout)
+        torch.testing.assert_close(s1[:, 0], src.sum(1), rtol=1e-3, atol=1e-3 * float(src.abs().sum(1).max()))
+        torch.testing.assert_close(s1[:, 1], (src * src).sum(1), rtol=1e-3, atol=1e-3 * float((src * src).sum(1).max()))
+        torch.testing.assert_close(s1.sum(0), s0.sum(0), rtol=1e-4, atol=1e-4 * float(s0.sum(0).abs().max()))
+    elif kw.get("stats_mode"):
         rows = (N * W * W + 127) // 128
         assert s1.shape == (rows, 2, Cout)
         src = F.pad(stat_src.reshape(-1, Cout), (0, 0, 0, rows * 128 - N * W * W)).reshape(rows, 128, Cout)

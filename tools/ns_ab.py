@@ -19,27 +19,24 @@ prep = ops.PreparedWeights(model, torch.bfloat16)
 lib = _C.lib()
 
 
-def variant(small, mlp, krot=200013, rules_off=0):
+def variant(small, mlp):
     lib.sihl_conv2d_small_enable(small)
-    lib.sihl_conv2d_krot(krot)
-    lib.sihl_conv2d_rules_off(rules_off)
     ops.MLP_KERNEL = mlp
 
 
-VARIANTS = [("default (small-level conv, register MLP, rotated K loops, P4 on 128x256)", 1, "rows", 200013, 0),
-            ("every workgroup its own K start (groups of 4 by default)", 1, "rows", 13, 0),
-            ("P4 3x3 on 128x128 single-stage tiles", 1, "rows", 200013, 8),
-            ("conv K loops in lockstep", 1, "rows", 0, 0),
-            ("general conv on P5-P7", 0, "rows", 200013, 0), ("LDS-tile MLP", 1, "tile", 200013, 0),
-            ("round-2 kernels (general conv, LDS-tile MLP, lockstep, 128x128)", 0, "tile", 0, 8)]
+# (round 4: the K-loop rotation / dispatch-rule switches exist in `make TUNING=1` libraries only; their A/Bs are
+# profiles/r03_ns_ab.txt)
+VARIANTS = [("default (conv_pyr on P5-P7, register MLP)", 1, "rows"),
+            ("conv_small on P5-P7 (round-3 kernel)", 2, "rows"),
+            ("general conv on P5-P7", 0, "rows"), ("LDS-tile MLP", 1, "tile")]
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 res = {v[0]: [] for v in VARIANTS}
 for rnd in range(rounds):
-    for name, small, mlp, krot, roff in VARIANTS:
-        variant(small, mlp, krot, roff)
+    for name, small, mlp in VARIANTS:
+        variant(small, mlp)
         r = bench.north_star_forward(model, dev, torch.bfloat16, 32, 512, iters=40)
         res[name].append(r["ms"])
-variant(1, "rows", 200013, 0)
+variant(1, "rows")
 for name in res:
     v = res[name]
     print(f"{name:80s} " + " ".join(f"{x:.3f}" for x in v) + f"   median {sorted(v)[len(v) // 2]:.3f} ms", flush=True)
