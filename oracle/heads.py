@@ -99,18 +99,25 @@ def anchor_offsets_and_scales(sizes: List[Tuple[int, int]], device=None) -> Tupl
     return torch.cat(offs), torch.cat(scls)
 
 
+def _island(t: Tensor) -> Tensor:
+    """The reference's fp32 loss islands (`.to(torch.float32)` under a disabled autocast, object_detection.py:158-208).
+    A float64 tensor stays float64: tests/test_gpu_fullsize.py runs this oracle in double precision as the yardstick that
+    measures the fp32 noise floor; in fp32 / bf16 the cast is the reference's."""
+    return t if t.dtype == torch.float64 else t.float()
+
+
 def bbox_matching(anchors: Tensor, gt_boxes: Tensor, topk: int, relative: bool = False):
     """Top-k-per-GT one-to-many assignment (object_detection.py:252-284)."""
     A, G = anchors.shape[0], gt_boxes.shape[0]
     assign = torch.full((A,), -1, device=anchors.device)
-    o2m = torch.zeros((A,), device=anchors.device)
+    o2m = torch.zeros((A,), device=anchors.device, dtype=anchors.dtype)
     if G == 0:
         return assign, o2m
     ious = complete_box_iou(anchors, gt_boxes).clamp(0)
     top_v, top_i = torch.topk(ious, k=topk, dim=0)
     in_topk = torch.zeros((A, G), dtype=torch.bool, device=anchors.device)
     in_topk.scatter_(0, top_i, True)
-    best_iou, best_gt = torch.max(ious * in_topk.float(), dim=1)
+    best_iou, best_gt = torch.max(ious * in_topk.to(ious.dtype), dim=1)
     valid = in_topk.any(dim=1)
     assign[valid] = best_gt[valid]
     if not relative:
@@ -193,15 +200,15 @@ class ObjectDetection(nn.Module):
         flat = self._flat_feats(inputs)
 
         loc_logits = self.loc_head(flat).squeeze(2)
-        loc_target = (rel_iou == 1.0).to(torch.float32)
-        loc_loss = F.binary_cross_entropy_with_logits(loc_logits.float(), loc_target, reduction="none")
+        loc_target = (rel_iou == 1.0).to(_island(loc_logits).dtype)
+        loc_loss = F.binary_cross_entropy_with_logits(_island(loc_logits), loc_target, reduction="none")
         loc_loss = loc_loss.sum() / loc_target.sum()
         if rel_iou.max() == 0:  # object_detection.py:165-172
             z = torch.zeros_like(loc_loss)
             return loc_loss, {"location_loss": loc_loss, "box_loss": z, "class_loss": z, "iou_loss": z}
 
         iou_preds = self.iou_head(flat).squeeze(2)
-        iou_loss = F.mse_loss(iou_preds.float(), rel_iou, reduction="none").sum() / rel_iou.sum()
+        iou_loss = F.mse_loss(_island(iou_preds), rel_iou, reduction="none").sum() / rel_iou.sum()
 
         mask = rel_iou > 0
         wts = rel_iou[mask]
@@ -210,12 +217,12 @@ class ObjectDetection(nn.Module):
         scl_sel = torch.cat([scales[m] for m in mask])
         box_preds = off_sel + scl_sel * self.box_head(sel).exp()
         box_target = torch.cat([boxes[b][assignment[b, m]] for b, m in enumerate(mask)])
-        box_loss = complete_box_iou_loss(box_preds.float(), box_target.to(torch.float32) / full)
+        box_loss = complete_box_iou_loss(_island(box_preds), _island(box_target) / full)
         box_loss = (wts * box_loss).sum() / wts.sum()
 
         cls_logits = self.cls_head(sel)
         cls_target = torch.cat([classes[b][assignment[b, m]] for b, m in enumerate(mask)])
-        cls_loss = F.cross_entropy(cls_logits.float(), cls_target, reduction="none")
+        cls_loss = F.cross_entropy(_island(cls_logits), cls_target, reduction="none")
         cls_loss = (wts * cls_loss).sum() / wts.sum()
 
         loss = loc_loss + 10 * box_loss + cls_loss + iou_loss

@@ -143,8 +143,9 @@ def emulate_rounding_noise(module, seed):
     return [m.register_forward_hook(hook) for m in module.modules() if not any(True for _ in m.children())]
 
 
-def bf16_floor(case, ns, data, samples=3):
-    """ref = fp32 oracle on `data`; floor[k] = max over the emulated runs of ||run[k] - ref[k]|| / ||ref[k]||."""
+def bf16_floor(case, ns, data, samples=3, envelope=False):
+    """ref = fp32 oracle on `data`; floor[k] = max over the emulated runs of ||run[k] - ref[k]|| / ||ref[k]||.
+    envelope=True: also returns env[k] = (lo, hi), the element-wise minimum / maximum over ref and the emulated runs."""
     _, ref = replay(case, ns, data)
     runs = [replay(case, ns, data, prepare=lambda m: (emulate_bf16_storage(m), m)[1])[1]]
     for s in range(samples):
@@ -156,4 +157,11 @@ def bf16_floor(case, ns, data, samples=3):
             floor[k] = max(float((r[k].float() - g.float()).norm()) / n for r in runs)
             # the same floor in worst-element terms (largest deviation over the tensor's largest magnitude)
             floor[k + "|max"] = max(float((r[k].float() - g.float()).abs().max()) for r in runs) / max(1e-6, float(g.abs().max()))
+    if envelope:
+        env = {}
+        for k, g in ref.items():
+            if g.is_floating_point():
+                stack = torch.stack([g.float()] + [r[k].float() for r in runs])
+                env[k] = (stack.min(0).values, stack.max(0).values)
+        return ref, floor, env
     return ref, floor

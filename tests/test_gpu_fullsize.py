@@ -32,10 +32,10 @@ def test_bifpn_od_training_step_512_fp32_matches_oracle():
              torch.tensor([[50.5, 260.25, 130.0, 420.75]])]
     classes = [torch.tensor([1, 44, 79]), torch.tensor([7])]
 
-    def run(neck, head, dev):
-        lv = [t.to(dev).requires_grad_(i >= 3) for i, t in enumerate(levels)]
+    def run(neck, head, dev, dtype=torch.float32):
+        lv = [t.to(dev, dtype).requires_grad_(i >= 3) for i, t in enumerate(levels)]
         feats = neck(lv)
-        loss, metrics = head.training_step(feats, [c.to(dev) for c in classes], [b.to(dev) for b in boxes])
+        loss, metrics = head.training_step(feats, [c.to(dev) for c in classes], [b.to(dev, dtype) for b in boxes])
         grads = torch.autograd.grad(loss, lv[3:6])
         return [f.detach().float().cpu() for f in feats[3:]], loss.detach().cpu(), \
             {k: v.detach().cpu() for k, v in metrics.items()}, [g.cpu() for g in grads]
@@ -52,7 +52,23 @@ def test_bifpn_od_training_step_512_fp32_matches_oracle():
     # an fp64 run of the same oracle by rms 0.8-1.3e-3 on exactly these tensors.  The gradient criterion is
     # therefore that noise floor (rms < 5e-3, worst element < 5 % of the tensor's scale), not 1e-4; forward
     # features, the loss and every loss component above ARE held to 1e-4.
-    for a, b in zip(hip_g, ref_g):
+    # That floor is MEASURED here, not quoted (round-3 review, weak 1c): the same oracle in fp64 on the same weights and
+    # inputs is the yardstick, floor = how far the fp32 oracle lies from it; the HIP fp32 gradients must lie within 3x that
+    # floor (+ 1e-4) of the fp64 gradients - and the floor itself must stay in the range that justifies the 5e-3 cap.
+    import copy
+    o64_neck, o64_head = copy.deepcopy(o_neck).double(), copy.deepcopy(o_head).double()
+    torch.set_default_dtype(torch.float64)  # the oracle's anchor grids and constants follow the default dtype
+    try:
+        _, _, _, ref64_g = run(o64_neck, o64_head, "cpu", torch.float64)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    for a, b, b64 in zip(hip_g, ref_g, ref64_g):
+        b64 = b64.float()
+        norm = float(b64.pow(2).mean().sqrt())
+        floor = float((b - b64).pow(2).mean().sqrt()) / norm
+        rms64 = float((a - b64).pow(2).mean().sqrt()) / norm
+        assert floor < 5e-3, f"fp32 oracle vs fp64 oracle: {floor:.2e} (the 5e-3 cap below assumes a floor near 1e-3)"
+        assert rms64 < 3 * floor + 1e-4, f"gradient rms error vs fp64 {rms64:.2e}, fp32-oracle floor {floor:.2e}"
         err = (a - b).abs()
         rms = float(err.pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
         assert rms < 5e-3, f"gradient rms-relative error {rms:.2e}"
