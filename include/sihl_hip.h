@@ -224,6 +224,10 @@ int sihl_blur_fuse_bwd(const void* dout, const void* a, const void* b, const voi
  *           a [N][2W][2W][Cin] (reflect-padded binomial blur, stride 2: layers/pooling.py:7-26), b, c [N][W][W][Cin];
  *           a_scale / a_shift optional (both or neither), as in sihl_blur_fuse; W = 8 or 4 only
  *   modes 1, 2: out = epilogue(conv3x3(m)); `merged` (optional, [N][W][W][Cin]) receives m (the weight gradient needs it).
+ *   emit (inference): the fusion node that CONSUMES `out`, computed in the epilogue from the workgroup's own 32-channel slice
+ *   of the whole map - 1: e_out [N][2W][2W][Cout] = softmax(e_fw)_0 * bilinear_x2(out) + softmax(e_fw)_1 * e_b;
+ *   2: e_out [N][W/2][W/2][Cout] = softmax(e_fw)_0 * blur_s2(out) + .._1 * e_b + .._2 * e_c; 0: none.  `out` may be NULL
+ *   when the emitted node was its only consumer (the AntialiasedDownscaler's conv in front of its blur).
  * wt [Cout][3][3][Cin]; Cin % 64 == 0, Cout % 32 == 0.  Epilogue as sihl_conv2d_fwd (bias -> [stats] -> pre-affine -> act ->
  * [stats] -> post-affine); statistics rows: sihl_pyr_conv_stat_rows(N, W) of [2][Cout] fp32 (one per 128 pixels on 16x16
  * maps, else one per tile: an 8x8 image / four 4x4 images), to be reduced by sihl_bn_finalize. */
@@ -232,7 +236,8 @@ int sihl_pyr_conv_stat_rows(int N, int W);
 int sihl_pyr_conv_fwd(const void* in, const void* wt, const float* bias, void* out, int N, int W, int Cin, int Cout, int act,
                       const float* pre_scale, const float* pre_shift, const float* post_scale, const float* post_shift,
                       int stats_mode, float* stats, long stats_bytes, int mode, const void* a, const void* b, const void* c,
-                      const float* fw, const float* a_scale, const float* a_shift, void* merged, hipStream_t stream);
+                      const float* fw, const float* a_scale, const float* a_shift, void* merged, int emit, const void* e_b,
+                      const void* e_c, const float* e_fw, void* e_out, hipStream_t stream);
 int sihl_fuse_sum(const void* x0, const void* x1, const void* x2, const float* wraw, void* out, long numel, int n,
                   int dtype, hipStream_t stream);
 int sihl_fuse_sum_bwd(const void* dout, const void* x0, const void* x1, const void* x2, const float* wraw, void* d0,
@@ -288,6 +293,7 @@ typedef struct sihl_mlp_call {
   void* out;
 } sihl_mlp_call;
 int sihl_mlp_rows_fwd_multi(const sihl_mlp_call* calls, int n, int act, int dtype, hipStream_t stream);
+int sihl_mlp_rows_config(int waves); /* test hook: 4 (default) = two 128-row workgroups per CU, 8 = one 256-row workgroup with a 4-stage weight ring (measured slower) */
 int sihl_mlp_rows_debug(int mode); /* timing ablations, `make TUNING=1` builds only (results invalid when non-zero) */
 int sihl_mlp_permute_k(const void* w_in, void* w_out, long Cout, int K, hipStream_t stream);
 int sihl_mlp_rows_fwd(const void* x, long x_stride, long rows, int Cin, int C, int nhidden, const void* const* w,

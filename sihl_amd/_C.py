@@ -32,6 +32,7 @@ SIGNATURES = {
     "sihl_mlp_fwd": (I, [P, L, L, I, I, I, P, P, P, P, F, I, I, P, I, I, P]),
     "sihl_mlp_rows_supported": (I, [L, I, I, I, I, I, I]),
     "sihl_mlp_rows_fwd_multi": (I, [P, I, I, I, P]),
+    "sihl_mlp_rows_config": (I, [I]),
     "sihl_mlp_rows_debug": (I, [I]),
     "sihl_mlp_permute_k": (I, [P, P, L, I, P]),
     "sihl_mlp_rows_fwd": (I, [P, L, L, I, I, I, P, P, P, P, F, I, I, P, I, I, P]),
@@ -82,7 +83,7 @@ SIGNATURES = {
     "sihl_blur_fuse": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "sihl_pyr_conv_supported": (I, [I, I, I, I, I]),
     "sihl_pyr_conv_stat_rows": (I, [I, I]),
-    "sihl_pyr_conv_fwd": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, I, P, L, I, P, P, P, P, P, P, P, P]),
+    "sihl_pyr_conv_fwd": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, I, P, L, I, P, P, P, P, P, P, P, I, P, P, P, P, P]),
     "sihl_blur_fuse_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "sihl_layernorm_act": (I, [P, P, L, I, P, P, F, I, P, P, I, P]),
     "sihl_layernorm_bwd_waves": (I, [L]),

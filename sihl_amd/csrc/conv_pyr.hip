@@ -57,6 +57,15 @@ struct PyrParams {
   const float* post_scale;
   const float* post_shift;
   float* stats;    // [rows][2][Cout]: one row per 128 pixels (16x16 maps) or per tile (8x8: per image; 4x4: per 4 images)
+  // EMIT: the fusion node that CONSUMES this conv's output y, computed in the epilogue for the workgroup's 32-channel slice
+  // (no recomputation: the slice of the whole map is here).  emit 1: e_out[N][2W][2W][Cout] = w0 * bilinear_x2(y) + w1 * e_b;
+  // emit 2: e_out[N][W/2][W/2][Cout] = w0 * blur_s2(y) + w1 * e_b + w2 * e_c (e_b, e_c, e_out of that size).  y is the bf16
+  // value the output tensor holds, so the result equals the stand-alone node kernel run on `out`.
+  const void* e_b;
+  const void* e_c;
+  const float* e_fw;
+  void* e_out;
+  int emit, write_y;  // write_y == 0: `out` itself is not stored (its only consumer was the emitted node)
   int N, Cin, Cout, M, act, stats_mode, gridN, tiles, k_rotate;
   unsigned long long* stamps;  // -DSIHL_PYR_STAMPS diagnostic builds: (s_memtime, s_memrealtime) marks of workgroup 0
 };
@@ -88,6 +97,7 @@ template <int W> struct PyrGeo {
   static constexpr int ITEMS = TM * 8 / PTHREADS;   // (pixel, 16-byte piece) items per thread per chunk of a fused loader
   static constexpr int EPI = TM * 4 / PTHREADS > 0 ? TM * 4 / PTHREADS : 1;  // (pixel, 8 channels) items per thread
   static constexpr int ROWS = TM / 128 > 0 ? TM / 128 : 1;  // statistics rows per tile
+  static constexpr int Y_OFF = (2 * TM * PST_STRIDE + 15) / 16 * 16;  // bf16 y tile of an emitting launch, behind the staging tiles
   static constexpr int PAR_OFF = 2 * BUF, RED_OFF = PAR_OFF + PPAR_BYTES;
   static constexpr int LDS = RED_OFF + PRED_BYTES;
   __device__ static __forceinline__ int swz(int pr, int pc) { return (2 * (pc >> 1) + (W == 4 ? 4 : 0) * pr) & 7; }
@@ -435,7 +445,69 @@ __global__ __launch_bounds__(PTHREADS, 2) void conv_pyr_kernel(const PyrParams p
       float o[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = pyr_act((v[e] + bias[e]) * s1[e] + t1[e], p.act) * s2[e] + t2[e];
-      if (m < p.M) *(uint4*)(out + (long)m * p.Cout + co) = pack16(o, bf16_t());
+      const uint4 packed = pack16(o, bf16_t());
+      if (m < p.M && p.write_y) *(uint4*)(out + (long)m * p.Cout + co) = packed;
+      if (p.emit) *(uint4*)(smem + Geo::Y_OFF + pl * (PBN * 2) + cg * 16) = packed;  // the slice's y, bf16: [pixel][32 channels]
+    }
+  }
+  if (p.emit) {
+    __syncthreads();
+    float ew[3];
+    pyr_softmax(p.e_fw, p.emit == 1 ? 2 : 3, ew);
+    const char* ys = smem + Geo::Y_OFF;
+    if (p.emit == 1) {
+      constexpr int WO = 2 * W, NIT = Geo::G * WO * WO * 4;  // (output pixel, 8 channels) items of the tile
+      for (int it = tid; it < NIT; it += PTHREADS) {
+        const int cg = it & 3, op = it >> 2;
+        const int seg = op / (WO * WO), r = op - seg * (WO * WO), oy = r / WO, ox = r - oy * WO;
+        const int n = img0 + seg;
+        if (n >= p.N) continue;
+        const PLerp ly = pyr_up2_src(oy, W), lx = pyr_up2_src(ox, W);
+        const char* y0 = ys + (seg * Geo::HW + ly.i0 * W) * (PBN * 2) + cg * 16;
+        const char* y1 = ys + (seg * Geo::HW + ly.i1 * W) * (PBN * 2) + cg * 16;
+        float f00[8], f01[8], f10[8], f11[8], o[8];
+        unpack16(*(const uint4*)(y0 + lx.i0 * (PBN * 2)), f00, bf16_t());
+        unpack16(*(const uint4*)(y0 + lx.i1 * (PBN * 2)), f01, bf16_t());
+        unpack16(*(const uint4*)(y1 + lx.i0 * (PBN * 2)), f10, bf16_t());
+        unpack16(*(const uint4*)(y1 + lx.i1 * (PBN * 2)), f11, bf16_t());
+        const long eo = (((long)n * WO + oy) * WO + ox) * p.Cout + n0 + cg * 8;
+        unpack16(*(const uint4*)((const bf16_t*)p.e_b + eo), o, bf16_t());
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          o[e] = node_fuse2(ew[0], ew[1], node_up2(ly.l0, ly.l1, lx.l0, lx.l1, f00[e], f01[e], f10[e], f11[e]), o[e]);
+        *(uint4*)((bf16_t*)p.e_out + eo) = pack16(o, bf16_t());
+      }
+    } else {
+      constexpr int WO = W / 2, NIT = Geo::G * WO * WO * 4;
+      const float k1[3] = {0.25f, 0.5f, 0.25f};
+      for (int it = tid; it < NIT; it += PTHREADS) {
+        const int cg = it & 3, op = it >> 2;
+        const int seg = op / (WO * WO), r = op - seg * (WO * WO), oy = r / WO, ox = r - oy * WO;
+        const int n = img0 + seg;
+        if (n >= p.N) continue;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const char* yr = ys + (seg * Geo::HW + pyr_reflect(2 * oy + dy - 1, W) * W) * (PBN * 2) + cg * 16;
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            float f[8];
+            unpack16(*(const uint4*)(yr + pyr_reflect(2 * ox + dx - 1, W) * (PBN * 2)), f, bf16_t());
+            const float kk = k1[dy] * k1[dx];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = __fmaf_rn(kk, f[e], acc[e]);
+          }
+        }
+        const long eo = (((long)n * WO + oy) * WO + ox) * p.Cout + n0 + cg * 8;
+        float fb[8], fc[8];
+        unpack16(*(const uint4*)((const bf16_t*)p.e_b + eo), fb, bf16_t());
+        unpack16(*(const uint4*)((const bf16_t*)p.e_c + eo), fc, bf16_t());
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = node_fuse3(ew[0], ew[1], ew[2], acc[e], fb[e], fc[e]);
+        *(uint4*)((bf16_t*)p.e_out + eo) = pack16(acc, bf16_t());
+      }
     }
   }
   PYR_STAMP(5);
@@ -481,7 +553,7 @@ int g_pyr = 1;  // test hook (sihl_conv2d_small_enable): 1 = this kernel, 2 = co
 template <int W, int MODE>
 int launch_pyr(const PyrParams& p, hipStream_t stream) {
   using Geo = PyrGeo<W>;
-  static_assert(Geo::LDS <= 160 * 1024 && 2 * Geo::TM * PST_STRIDE <= 2 * Geo::BUF, "LDS budget");
+  static_assert(Geo::LDS <= 160 * 1024 && Geo::Y_OFF + Geo::TM * PBN * 2 <= 2 * Geo::BUF, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_pyr_kernel<W, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS);
@@ -554,6 +626,7 @@ int sihl_pyr_launch(const ConvParams& c, hipStream_t stream) {
   p.bias = c.bias; p.pre_scale = c.pre_scale; p.pre_shift = c.pre_shift; p.post_scale = c.post_scale; p.post_shift = c.post_shift;
   p.stats = c.stats;
   p.N = c.N; p.Cin = c.Cin; p.Cout = c.Cout; p.act = c.act; p.stats_mode = c.stats_mode;
+  p.write_y = 1;
   return pyr_launch(p, c.W, 0, stream);
 }
 
@@ -573,8 +646,11 @@ int sihl_pyr_conv_stat_rows(int N, int W) {
 int sihl_pyr_conv_fwd(const void* in, const void* wt, const float* bias, void* out, int N, int W, int Cin, int Cout, int act,
                       const float* pre_scale, const float* pre_shift, const float* post_scale, const float* post_shift,
                       int stats_mode, float* stats, long stats_bytes, int mode, const void* a, const void* b, const void* c,
-                      const float* fw, const float* a_scale, const float* a_shift, void* merged, hipStream_t stream) {
-  if (!wt || !out || !pyr_shape_ok(N, W, Cin, Cout, mode)) return SIHL_EARG;
+                      const float* fw, const float* a_scale, const float* a_shift, void* merged, int emit, const void* e_b,
+                      const void* e_c, const float* e_fw, void* e_out, hipStream_t stream) {
+  if (!wt || !pyr_shape_ok(N, W, Cin, Cout, mode)) return SIHL_EARG;
+  if (emit < 0 || emit > 2 || (!out && !emit)) return SIHL_EARG;
+  if (emit && (!e_b || !e_fw || !e_out || (emit == 2 && (!e_c || W % 2)))) return SIHL_EARG;
   if (mode == 0 ? !in : (!a || !b || !fw || (mode == 2 && !c))) return SIHL_EARG;
   if ((a_scale == nullptr) != (a_shift == nullptr) || (a_scale && mode != 2)) return SIHL_EARG;
   if (act < SIHL_ACT_NONE || act > SIHL_ACT_SIGMOID || stats_mode < 0 || stats_mode > 2) return SIHL_EARG;
@@ -582,6 +658,7 @@ int sihl_pyr_conv_fwd(const void* in, const void* wt, const float* bias, void* o
   PyrParams p = {};
   p.in = in; p.wt = wt; p.out = out; p.a = a; p.b = b; p.c = c; p.fw = fw; p.a_scale = a_scale; p.a_shift = a_shift;
   p.merged = merged;
+  p.emit = emit; p.e_b = e_b; p.e_c = e_c; p.e_fw = e_fw; p.e_out = e_out; p.write_y = out != nullptr;
   p.bias = bias; p.pre_scale = pre_scale; p.pre_shift = pre_shift; p.post_scale = post_scale; p.post_shift = post_shift;
   p.stats = stats_mode ? stats : nullptr;
   p.N = N; p.Cin = Cin; p.Cout = Cout; p.act = act; p.stats_mode = stats_mode;

@@ -53,9 +53,8 @@ struct MlpRowsBatch {
   int first_block[MLPR_MAXN + 1];  // workgroups first_block[k] .. first_block[k + 1] - 1 run MLP k
 };
 
-constexpr int RBM = 128, RTHREADS = 256, RKCB = 128, RKCE = 64;
+constexpr int RKCB = 128, RKCE = 64;
 constexpr int RSTAGE = 256 * RKCB;  // one weight stage: 256 out-channels x 64 k (32 KiB)
-constexpr int RRING = 2 * RSTAGE;
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -96,8 +95,13 @@ __device__ __forceinline__ void mlp_rows_stage(f32x16_t (&acc)[8], const uint4 (
 // SILU: 1 = SiLU, 0 = max(t, floor) (floor = 0: ReLU, -inf: none).  LASTB: 32-channel blocks of the last layer (Cout <= 32 LASTB).
 // Hidden layers are full width (C == 256: 8 blocks, compile-time - a run-time block count puts the accumulators behind
 // branches and hipcc then spills them).
-template <int SILU, int LASTB>
-__global__ __launch_bounds__(RTHREADS, 2) void mlp_rows_kernel(const MlpRowsBatch pb, const float floor_) {
+// NW waves of 32 rows each per workgroup, NS weight stages in the ring.  (4, 2): two workgroups per CU, each streaming every
+// layer's weights for its 128 rows; (8, NS >= 3): ONE workgroup of 256 rows per CU - the same 8 waves per CU, half the
+// weight bytes through L2 -> LDS per row (tools/mlp_probe.py ablations: the weight stream was the largest phase) and
+// NS - 1 stages in flight instead of one.
+template <int SILU, int LASTB, int NW, int NS>
+__global__ __launch_bounds__(NW * 64, 2) void mlp_rows_kernel(const MlpRowsBatch pb, const float floor_) {
+  constexpr int RBM = NW * 32, RRING = NS * RSTAGE, PPW = 32 / NW;  // rows per workgroup; ring bytes; DMA pieces per wave and stage
   // several MLPs in one launch (the class and box heads of a detection head run over the same few thousand rows: each
   // alone fills a tenth of the chip for the same 35 us)
   int which = 0;
@@ -127,16 +131,17 @@ __global__ __launch_bounds__(RTHREADS, 2) void mlp_rows_kernel(const MlpRowsBatc
     for (int k = 0; k < 16; ++k)
       xk[k] = (m < p.rows && 16 * k + 8 * fh < p.Cin) ? *(const uint4*)(xr + 16 * k) : make_uint4(0u, 0u, 0u, 0u);
   }
-  for (int l = 0; l <= p.nhidden; ++l) {
-    const int Co = l < p.nhidden ? 256 : p.Cout;
-    pbias[l * 256 + tid] = (p.bias[l] && tid < Co) ? p.bias[l][tid] : 0.f;
-    if (l < p.nhidden) {
-      pgamma[l * 256 + tid] = p.gamma[l][tid];
-      pbeta[l * 256 + tid] = p.beta[l][tid];
+  if (tid < 256)
+    for (int l = 0; l <= p.nhidden; ++l) {
+      const int Co = l < p.nhidden ? 256 : p.Cout;
+      pbias[l * 256 + tid] = (p.bias[l] && tid < Co) ? p.bias[l][tid] : 0.f;
+      if (l < p.nhidden) {
+        pgamma[l * 256 + tid] = p.gamma[l][tid];
+        pbeta[l * 256 + tid] = p.beta[l][tid];
+      }
     }
-  }
 
-  // ---- weight stages: one sequence over all layers (layer, K-chunk), slot = stage & 1
+  // ---- weight stages: one sequence over all layers (layer, K-chunk), slot = stage % NS
   int i_l = 0, i_kc = 0, i_slot = 0, issued = 0;
   auto issue_stage = [&]() {
     const int K = i_l == 0 ? p.Cin : 256;
@@ -145,34 +150,48 @@ __global__ __launch_bounds__(RTHREADS, 2) void mlp_rows_kernel(const MlpRowsBatc
     const v4i_t w_rsrc = make_rsrc(p.w[i_l], (unsigned)((long)Co * K * 2));
     const unsigned dst = lds_base + i_slot * RSTAGE;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int piece = wave * 8 + j;  // 8 rows x 128 B per wave-instruction
-      if (piece * 8 >= live) continue;  // wave-uniform
+    for (int j = 0; j < PPW; ++j) {
+      const int piece = wave * PPW + j;  // 8 rows x 128 B per wave-instruction
+      if (NS == 2 && piece * 8 >= live) continue;  // wave-uniform (deeper rings count their pieces: every piece is issued)
       const int row = piece * 8 + (lane >> 3), pos = lane & 7;
       const int ch = i_kc * RKCE + ((pos ^ ((row >> 1) & 7)) << 3);
       const bool ok = row < Co && ch < K;
       dma16(ok ? (unsigned)(((long)row * K + ch) * 2) : OOB, dst + piece * 1024, w_rsrc);
     }
     ++issued;
-    i_slot ^= 1;
+    i_slot = i_slot + 1 == NS ? 0 : i_slot + 1;
     if (++i_kc == (i_l == 0 ? nk_in : 4)) { i_kc = 0; ++i_l; }
   };
-  issue_stage();
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0)
+    if (issued < total) issue_stage();
   __syncthreads();  // the parameter vectors are in LDS
   // (Tried: a start delay for alternate workgroups, to put the two workgroups of a CU out of phase - one normalising while
   // the other multiplies.  Monotonically slower, 143.5 -> 160.9 us for 0 -> 6 x 4096 cycles: not kept.)
 
   const float inv_c = 1.f / 256.f;
-  int slot = 0;
+  int slot = 0, chunk = 0;
   f32x16_t acc[8];
+  // stage `chunk` has landed when at most the stages issued behind it are in flight: min(NS - 2, total - 1 - chunk) of them
+  auto wait_stage = [&]() {
+    if constexpr (NS == 2) {
+      wait_vm_keep<0>();
+    } else {
+      const int later = min(NS - 2, total - 1 - chunk);
+      if (later >= 2) wait_vm_keep<2 * PPW>();
+      else if (later == 1) wait_vm_keep<PPW>();
+      else wait_vm_keep<0>();
+    }
+  };
   // one K chunk: stage (l, kc) has landed for every wave and everyone is done reading the other slot; refill that one
 #define MLPR_CHUNK(NB, KC)                                                            \
   do {                                                                                \
-    wait_vm_keep<0>();                                                                \
+    wait_stage();                                                                     \
     __syncthreads();                                                                  \
     if (issued < total && !(MLPR_DBG(p) & 2)) issue_stage();                          \
     if (!(MLPR_DBG(p) & 4)) mlp_rows_stage<NB, KC>(acc, xk, smem + slot * RSTAGE + fr * RKCB, fh, fsw); \
-    slot ^= 1;                                                                        \
+    slot = slot + 1 == NS ? 0 : slot + 1;                                             \
+    ++chunk;                                                                          \
   } while (0)
 
   for (int l = 0; l < p.nhidden; ++l) {
@@ -302,21 +321,32 @@ __global__ void mlp_permute_k_kernel(const uint2* __restrict__ in, uint2* __rest
 }
 
 int g_mlp_rows_dbg = 0;
-template <int SILU, int LASTB>
-int launch_mlp_rows(const MlpRowsBatch& pb, int n, float floor_, hipStream_t stream) {
+// test hook (sihl_mlp_rows_config).  Default 4: two 4-wave workgroups per CU with a 2-stage ring.  8 - ONE 256-row workgroup
+// per CU, 4-stage ring: half the weight bytes through L2 -> LDS per row and three stages in flight - was built in round 4 on
+// the round-3 ablation that named the weight stream the longest phase, and is SLOWER: north-star forward 2.111 against
+// 2.080 ms in one process (profiles/r04_ns_ab_mlp_waves.txt).  Two independent workgroups drift apart - one normalises
+// (VALU) while the other multiplies - and eight waves behind one barrier per stage do not.
+int g_mlp_rows_waves = 4;
+template <int SILU, int LASTB, int NW, int NS>
+int launch_mlp_rows_cfg(const MlpRowsBatch& pb, int n, float floor_, hipStream_t stream) {
   int nh = 0;
   for (int k = 0; k < n; ++k) nh = pb.p[k].nhidden > nh ? pb.p[k].nhidden : nh;
-  const int lds = RRING + (3 * nh + 1) * 256 * (int)sizeof(float);
+  const int lds = NS * RSTAGE + (3 * nh + 1) * 256 * (int)sizeof(float);
   if (lds > 160 * 1024) return SIHL_EARG;
   static int attr_lds = 0;
   if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute((const void*)mlp_rows_kernel<SILU, LASTB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)mlp_rows_kernel<SILU, LASTB, NW, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     attr_lds = lds;
   }
-  hipLaunchKernelGGL((mlp_rows_kernel<SILU, LASTB>), dim3(pb.first_block[n]), dim3(RTHREADS), lds, stream, pb, floor_);
+  hipLaunchKernelGGL((mlp_rows_kernel<SILU, LASTB, NW, NS>), dim3(pb.first_block[n]), dim3(NW * 64), lds, stream, pb, floor_);
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
+}
+template <int SILU, int LASTB>
+int launch_mlp_rows(const MlpRowsBatch& pb, int n, float floor_, hipStream_t stream) {
+  if (g_mlp_rows_waves == 8) return launch_mlp_rows_cfg<SILU, LASTB, 8, 4>(pb, n, floor_, stream);
+  return launch_mlp_rows_cfg<SILU, LASTB, 4, 2>(pb, n, floor_, stream);
 }
 
 }  // namespace
@@ -329,6 +359,14 @@ int sihl_mlp_rows_supported(long rows, int Cin, int C, int Cout, int nhidden, in
   return dtype == SIHL_BF16 && rows > 0 && rows < (1L << 30) && Cin > 0 && Cin <= 256 && Cin % 8 == 0 && Cout > 0 &&
          Cout <= 256 && nhidden >= 1 && nhidden <= MLPR_MAXL && C == 256 &&
          (act == SIHL_ACT_SILU || act == SIHL_ACT_RELU || act == SIHL_ACT_NONE);
+}
+
+// Test hook: waves per workgroup of sihl_mlp_rows_fwd - 4 (default: two 128-row workgroups per CU, 2-stage weight ring) or 8
+// (one 256-row workgroup per CU, 4-stage ring: measured slower, kept parity-tested as the A/B arm).
+int sihl_mlp_rows_config(int waves) {
+  if (waves != 4 && waves != 8) return SIHL_EARG;
+  g_mlp_rows_waves = waves;
+  return SIHL_OK;
 }
 
 // Tuning ablation (`make TUNING=1` builds only; results invalid when non-zero): see MlpRowsParams::dbg.
@@ -385,7 +423,8 @@ int sihl_mlp_rows_fwd_multi(const sihl_mlp_call* calls, int n, int act, int dtyp
       p.beta[l] = c.beta[l];
     }
     pb.first_block[k] = blocks;
-    blocks += (p.rows + RBM - 1) / RBM;
+    const int rbm = g_mlp_rows_waves == 8 ? 256 : 128;  // rows per workgroup of the configuration launch_mlp_rows picks
+    blocks += (p.rows + rbm - 1) / rbm;
     maxco = c.Cout > maxco ? c.Cout : maxco;
   }
   for (int k = n; k <= MLPR_MAXN; ++k) pb.first_block[k] = k == n ? blocks : 0x7fffffff;

@@ -97,6 +97,22 @@ class _ConvBlock(nn.Sequential):
             ops.bump_counter(bn.num_batches_tracked)
         return y
 
+    def forward_nhwc_emit(self, x: Tensor, emit, write_y: bool = True):
+        """Inference only: this block on ``x`` AND the fusion node that consumes its output, in one launch (conv_pyr.hip's
+        epilogue computes the node for each workgroup's channel slice of the whole map).  emit = ("up2", b, wraw) ->
+        softmax(wraw)_0 * bilinear_x2(y) + .._1 * b, or ("blur", b, c, wraw) -> softmax(wraw)_0 * blur_s2(y) + .._1 * b +
+        .._2 * c.  Returns (y, node) - y None when write_y is False - or None when the block, the mode or the shapes are
+        outside that kernel (the caller then runs the block and the node's own kernel)."""
+        if self.training or torch.is_grad_enabled() or self.order != "act_norm" or self.act not in (None, "relu"):
+            return None
+        conv, bn = self._parts()
+        if (bn is None or conv.groups != 1 or conv.padding_mode != "zeros" or conv.kernel_size != (3, 3) or conv.stride != (1, 1)
+                or conv.padding != (1, 1) or conv.dilation != (1, 1) or not bn.track_running_stats or not bn.affine
+                or any(isinstance(m, (nn.GroupNorm, nn.Softplus, nn.Softmax)) for m in self)):
+            return None
+        return ops.conv_block_emit(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, act=self.act,
+                                   eps=bn.eps, emit=emit, write_y=write_y)
+
     def forward_nhwc_into(self, x: Tensor, out: Tensor, out_image_stride: int) -> bool:
         """Inference only: write this block's output for image n at ``out`` + n * out_image_stride elements (a slice of a
         larger buffer).  Returns False - and writes nothing - when the block is not the plain case the one-launch path

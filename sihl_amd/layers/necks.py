@@ -61,31 +61,67 @@ class BiFPNLayer(nn.Module):
         self.down_fusions = _modules(hops, lambda _: FastNormalizedFusion(3))
         self.down_convs = _modules(hops, conv)
 
-    def forward_nhwc(self, feats: Sequence[Tensor]) -> List[Tensor]:
+    def forward_nhwc(self, feats: Sequence[Tensor], first_merged: Tensor = None, next_up_weights: Tensor = None,
+                     return_next: bool = False):
+        """first_merged: the first top-down node (fuse_up2 of the two top maps), when the caller already has it (the previous
+        layer's last conv emitted it); next_up_weights: the NEXT layer's first top-down fusion weights - with return_next the
+        result is (maps, that layer's first node or None).
+
+        Inference on the small maps (conv_pyr.hip's shapes) runs each conv block together with the fusion node that consumes
+        its output - the node is computed in the conv's epilogue from the workgroup's own channel slice of the whole map
+        (ConvNormAct.forward_nhwc_emit) - so the top of the pyramid is one launch per conv; everywhere else, and in training,
+        every node is its own kernel (or, opt-in, part of the consuming conv's loader: forward_fused_node)."""
         top = self.num_levels - 1
         if len(feats) != self.num_levels:
             raise AssertionError((len(feats), self.num_levels))
         # descend: module k works at level top-1-k and consumes the map produced one level above it
         down = {top: feats[top]}
+        merged = first_merged
         for k in range(top):
             lvl = top - 1 - k
-            # node + conv block as one launch on the small maps (csrc/conv_pyr.hip), else fusion kernel, then conv
-            y = self.up_convs[k].forward_fused_node(("up2", down[lvl + 1], feats[lvl], self.up_fusions[k].weights))
-            if y is None:
-                y = self.up_convs[k].forward_nhwc(ops.fuse_up2(down[lvl + 1], feats[lvl], self.up_fusions[k].weights))
-            down[lvl] = y
+            conv, wts = self.up_convs[k], self.up_fusions[k].weights
+            nxt = None  # the node one level further down, if this conv can emit it
+            if merged is None:
+                # node + conv block as one launch on the small maps (opt-in), else fusion kernel, then conv
+                y = conv.forward_fused_node(("up2", down[lvl + 1], feats[lvl], wts))
+                if y is not None:
+                    down[lvl] = y
+                    continue
+                merged = ops.fuse_up2(down[lvl + 1], feats[lvl], wts)
+            if k + 1 < top:
+                got = conv.forward_nhwc_emit(merged, ("up2", feats[lvl - 1], self.up_fusions[k + 1].weights))
+                if got is not None:
+                    down[lvl], nxt = got
+            if nxt is None:
+                down[lvl] = conv.forward_nhwc(merged)
+            merged = nxt
         # ascend: module k produces level k+1 from (blurred conv of level k, the input, the top-down map)
         out = [down[0]]
+        next_first = None
         for k in range(top):
-            # conv block of the downscaler; its blur - and in training its BatchNorm affine - is fused into the merge below
-            affine = ops.DeferredAffine()
-            pre = self.downscalers[k][0].forward_nhwc(out[k], defer=affine)
             w3 = self.down_fusions[k].weights
-            y = self.down_convs[k].forward_fused_node(("blur", pre, feats[k + 1], down[k + 1], w3, affine))
-            if y is None:
-                y = self.down_convs[k].forward_nhwc(ops.blur_fuse(pre, feats[k + 1], down[k + 1], w3, a_affine=affine))
-            out.append(y)
-        return out
+            merged = None
+            # the downscaler's conv block with the bottom-up node in its epilogue (its own output has no other reader) ...
+            got = self.downscalers[k][0].forward_nhwc_emit(out[k], ("blur", feats[k + 1], down[k + 1], w3), write_y=False)
+            if got is not None:
+                merged = got[1]
+            else:
+                # ... or the conv block; its blur - and in training its BatchNorm affine - is fused into the merge below
+                affine = ops.DeferredAffine()
+                pre = self.downscalers[k][0].forward_nhwc(out[k], defer=affine)
+                y = self.down_convs[k].forward_fused_node(("blur", pre, feats[k + 1], down[k + 1], w3, affine))
+                if y is not None:
+                    out.append(y)
+                    continue
+                merged = ops.blur_fuse(pre, feats[k + 1], down[k + 1], w3, a_affine=affine)
+            y = None
+            if k == top - 1 and next_up_weights is not None:
+                # the top map's conv also emits the NEXT layer's first top-down node: up2(new top) (+) new map below it
+                got = self.down_convs[k].forward_nhwc_emit(merged, ("up2", out[k], next_up_weights))
+                if got is not None:
+                    y, next_first = got
+            out.append(y if y is not None else self.down_convs[k].forward_nhwc(merged))
+        return (out, next_first) if return_next else out
 
     def forward(self, inputs: Sequence[Tensor]) -> List[Tensor]:
         return [ops.nchw_view(t) for t in self.forward_nhwc([ops.nhwc(t) for t in inputs])]
@@ -114,8 +150,10 @@ class BiFPN(nn.Module):
                 for i, lat in enumerate(self.lateral_connections)]
         for extra in self.downscalers:
             maps.append(extra.forward_nhwc(maps[-1]))
-        for layer in self.layers:
-            maps = layer.forward_nhwc(maps)
+        first = None
+        for i, layer in enumerate(self.layers):
+            nxt = self.layers[i + 1].up_fusions[0].weights if i + 1 < len(self.layers) else None
+            maps, first = layer.forward_nhwc(maps, first_merged=first, next_up_weights=nxt, return_next=True)
         return _splice(inputs, self.bottom_level, self.top_level, maps)
 
 

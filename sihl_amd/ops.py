@@ -389,13 +389,18 @@ def pyr_conv_supported(N: int, W: int, Cin: int, Cout: int, mode: int, dtype) ->
 
 def pyr_conv_raw(w: Tensor, x: Optional[Tensor] = None, fuse=None, bias: Optional[Tensor] = None, act: Optional[str] = None,
                  pre: Optional[Tuple[Tensor, Tensor]] = None, post: Optional[Tuple[Tensor, Tensor]] = None,
-                 stats_mode: int = 0, want_merged: bool = False):
+                 stats_mode: int = 0, want_merged: bool = False, emit=None, write_y: bool = True):
     """3x3 / pad 1 conv of a small square map (16, 8 or 4 wide, bf16) with its fusion node folded into the loader
     (sihl_pyr_conv_fwd, csrc/conv_pyr.hip).  Input: ``x`` (N, W, W, Cin), or ``fuse`` =
     ("up2", a, b, wraw)                  -> softmax(wraw)_0 * bilinear_x2(a) + softmax(wraw)_1 * b,  or
     ("blur", a, b, c, wraw, a_affine)    -> softmax(wraw)_0 * (blur_s2(a) * scale + shift) + .._1 * b + .._2 * c
     (a_affine = (scale, shift) or None).  Returns (y, stats, merged): stats fp32 [rows][2][Cout] when stats_mode != 0,
-    merged = the conv's input when want_merged (training: the weight gradient reads it)."""
+    merged = the conv's input when want_merged (training: the weight gradient reads it).
+
+    emit (inference): the fusion node that consumes y, computed in the same launch - ("up2", b, wraw) ->
+    softmax(wraw)_0 * bilinear_x2(y) + .._1 * b with b (N, 2W, 2W, Cout); ("blur", b, c, wraw) -> softmax(wraw)_0 *
+    blur_s2(y) + .._1 * b + .._2 * c with b, c (N, W/2, W/2, Cout).  The return value then has a 4th entry, the node;
+    write_y=False skips storing y itself (returned as None)."""
     Cout, KH, KW, Cin = w.shape
     assert KH == 3 and KW == 3
     a = b = c = wraw = a_scale = a_shift = None
@@ -411,8 +416,18 @@ def pyr_conv_raw(w: Tensor, x: Optional[Tensor] = None, fuse=None, bias: Optiona
     N, W = ref.shape[0], ref.shape[2]
     if ref.shape[1] != W or ref.shape[3] != Cin or not pyr_conv_supported(N, W, Cin, Cout, mode, ref.dtype):
         raise ValueError(f"pyr_conv_raw: unsupported problem {tuple(ref.shape)} -> {Cout}, mode {mode}, {ref.dtype}")
-    out = torch.empty((N, W, W, Cout), dtype=ref.dtype, device=ref.device)
+    out = torch.empty((N, W, W, Cout), dtype=ref.dtype, device=ref.device) if (write_y or emit is None) else None
     merged = torch.empty_like(ref) if (want_merged and mode != 0) else None
+    e_mode, e_b, e_c, e_fw, e_out = 0, None, None, None, None
+    if emit is not None:
+        e_mode = 1 if emit[0] == "up2" else 2
+        e_b, e_fw = emit[1], emit[-1]
+        e_c = emit[2] if e_mode == 2 else None
+        Wo = 2 * W if e_mode == 1 else W // 2
+        want = (N, Wo, Wo, Cout)
+        if tuple(e_b.shape) != want or e_b.dtype != ref.dtype or (e_c is not None and (tuple(e_c.shape) != want or e_c.dtype != ref.dtype)):
+            raise ValueError(f"pyr_conv_raw: emit inputs must be {want} {ref.dtype}")
+        e_out = torch.empty(want, dtype=ref.dtype, device=ref.device)
     stats, stats_bytes = None, 0
     if stats_mode:
         stats = torch.empty((_sized("sihl_pyr_conv_stat_rows", N, W), 2, Cout), dtype=torch.float32, device=ref.device)
@@ -420,8 +435,11 @@ def pyr_conv_raw(w: Tensor, x: Optional[Tensor] = None, fuse=None, bias: Optiona
     rc = _C.lib().sihl_pyr_conv_fwd(
         _p(x), _p(w), _p(bias), _p(out), N, W, Cin, Cout, ACT[act],
         _p(pre[0]) if pre else None, _p(pre[1]) if pre else None, _p(post[0]) if post else None, _p(post[1]) if post else None,
-        stats_mode, _p(stats), stats_bytes, mode, _p(a), _p(b), _p(c), _p(wraw), _p(a_scale), _p(a_shift), _p(merged), _stream())
+        stats_mode, _p(stats), stats_bytes, mode, _p(a), _p(b), _p(c), _p(wraw), _p(a_scale), _p(a_shift), _p(merged),
+        e_mode, _p(e_b), _p(e_c), _p(e_fw), _p(e_out), _stream())
     check(rc, "sihl_pyr_conv_fwd")
+    if emit is not None:
+        return out, stats, (x if mode == 0 else merged), e_out
     return out, stats, (x if mode == 0 else merged)
 
 
@@ -1010,6 +1028,31 @@ def fused_node_conv_block(fuse, weight, bias, gamma, beta, running_mean, running
         defer = None
     return ConvBlockFn.apply(m, weight, bias, gamma, beta, running_mean, running_var, cfg, None, None, None, None, defer,
                              (s, stats))
+
+
+EMIT_NODES = os.environ.get("SIHL_EMIT_NODES", "1") != "0"  # A/B and test switch: False = every fusion node its own launch
+
+
+def conv_block_emit(x: Tensor, weight, bias, gamma, beta, running_mean, running_var, *, act, eps, emit, write_y=True):
+    """Inference: a 3x3 conv -> act -> BatchNorm block on a small square map AND the fusion node that consumes its output
+    in one launch (sihl_pyr_conv_fwd with `emit`).  Returns (y or None, node), or None when outside the kernel's shapes."""
+    N, H, W, Cin = x.shape
+    Cout = weight.shape[0]
+    kind = emit[0]
+    if (not EMIT_NODES or not x.is_cuda or H != W or not pyr_conv_supported(N, W, Cin, Cout, 0, x.dtype)
+            or (kind == "blur" and W % 2) or _C.lib().sihl_conv2d_small_mode() != 1):
+        return None
+    Wo = 2 * W if kind == "up2" else W // 2
+    others = emit[1:-1]
+    if any(tuple(t.shape) != (N, Wo, Wo, Cout) or t.dtype != x.dtype for t in others):
+        return None
+    prep = prepared(weight, x.dtype)
+    w = prep.w if prep is not None else weight_khwc(weight, x.dtype)
+    scale, shift = bn_eval_affine(gamma, beta, running_mean, running_var, eps)
+    wr = emit[-1].detach().float().contiguous()
+    raw = (kind,) + tuple(t.detach().contiguous() for t in others) + (wr,)
+    y, _, _, node = pyr_conv_raw(w, x=x.detach().contiguous(), bias=bias, act=act, post=(scale, shift), emit=raw, write_y=write_y)
+    return y, node
 
 
 # ----------------------------------------------------------------------------- fusion nodes

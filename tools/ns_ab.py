@@ -19,8 +19,9 @@ prep = ops.PreparedWeights(model, torch.bfloat16)
 lib = _C.lib()
 
 
-def variant(small, mlp):
+def variant(small, mlp, waves=4):
     lib.sihl_conv2d_small_enable(small)
+    lib.sihl_mlp_rows_config(waves)
     ops.MLP_KERNEL = mlp
 
 
@@ -28,12 +29,13 @@ def variant(small, mlp):
 # profiles/r03_ns_ab.txt)
 VARIANTS = [("default (conv_pyr on P5-P7, register MLP)", 1, "rows"),
             ("conv_small on P5-P7 (round-3 kernel)", 2, "rows"),
-            ("general conv on P5-P7", 0, "rows"), ("LDS-tile MLP", 1, "tile")]
+            ("general conv on P5-P7", 0, "rows"), ("LDS-tile MLP", 1, "tile"),
+            ("register MLP as one 8-wave workgroup per CU, 4-stage ring", 1, "rows", 8)]
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 res = {v[0]: [] for v in VARIANTS}
 for rnd in range(rounds):
-    for name, small, mlp in VARIANTS:
-        variant(small, mlp)
+    for name, small, mlp, *rest in VARIANTS:
+        variant(small, mlp, *rest)
         r = bench.north_star_forward(model, dev, torch.bfloat16, 32, 512, iters=40)
         res[name].append(r["ms"])
 variant(1, "rows")
