@@ -174,13 +174,24 @@ class InstanceSegmentation(nn.Module):
         return loss, {"location_loss": loc_loss, "mask_loss": mask_loss, "class_loss": cls_loss}
 
     def on_validation_start(self) -> None:
+        from sihl_amd.metrics import MaskMeanAveragePrecision
+
         self._val_losses: List[Tensor] = []
+        self.map_computer = MaskMeanAveragePrecision([1, min(self.max_instances, 10), self.max_instances])
 
     def validation_step(self, inputs, classes, masks):
+        """Reference :308-320: mask mAP (COCO protocol, iou_type "segm") of ``forward``'s detections, thresholded at 0.5,
+        plus the training loss on the same inputs.  The per-image IoU matrices are computed on the device."""
+        with torch.no_grad():
+            _, scores, pred_classes, pred_masks = self.forward(inputs)
+        self.map_computer.update(
+            [{"scores": s, "labels": c, "masks": m > 0.5} for s, c, m in zip(scores, pred_classes, pred_masks)],
+            [{"labels": c, "masks": m > 0.5} for c, m in zip(classes, masks)])
         loss, metrics = self.training_step(inputs, classes, masks, is_validating=True)
         self._val_losses.append(loss.detach())
         return loss, metrics
 
     def on_validation_end(self) -> Dict[str, float]:
-        # mask mAP needs a COCO evaluator (torchmetrics + faster_coco_eval in the reference): out of scope
-        return {"loss": torch.stack(self._val_losses).mean().item() if self._val_losses else float("nan")}
+        metrics = self.map_computer.compute() if hasattr(self, "map_computer") else {}
+        metrics["loss"] = torch.nanmean(torch.stack(self._val_losses).float()).item() if self._val_losses else float("nan")
+        return metrics

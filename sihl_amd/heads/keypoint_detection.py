@@ -182,13 +182,28 @@ class KeypointDetection(nn.Module):
         return loss, {"location_loss": loc_loss, "keypoint_loss": kp_loss, "presence_loss": presence_loss}
 
     def on_validation_start(self) -> None:
+        from sihl_amd.metrics import PercentageOfCorrectKeypoints
+
         self._val_losses: List[Tensor] = []
+        self.pck_computer = PercentageOfCorrectKeypoints(threshold=0.05)
 
     def validation_step(self, inputs, keypoints, presence):
+        """Reference :322-341: PCK@0.05 of ``forward``'s instances (keypoints as image fractions, the first num_instances of
+        every image) against the ground truth, plus the training loss on the same inputs."""
+        B, _, H, W = inputs[0].shape
+        with torch.no_grad():
+            num_instances, _, keypoint_scores, pred_keypoints = self.forward(inputs)
+        full = torch.tensor([[[W, H]]], device=pred_keypoints.device, dtype=torch.float32)
+        counts = num_instances.tolist()  # one host read per validation step (the metric pairs instances on the host anyway)
+        for b in range(B):
+            k = int(counts[b])
+            self.pck_computer.update(pred_keypoints[b, :k].float() / full, keypoint_scores[b, :k],
+                                     keypoints[b].to(full.device).float() / full, presence[b])
         loss, metrics = self.training_step(inputs, keypoints=keypoints, presence=presence, is_validating=True)
         self._val_losses.append(loss.detach())
         return loss, metrics
 
     def on_validation_end(self) -> Dict[str, float]:
-        # PCK needs the reference's torchmetrics-based PercentageOfCorrectKeypoints: out of scope
-        return {"loss": torch.stack(self._val_losses).mean().item() if self._val_losses else float("nan")}
+        metrics = self.pck_computer.compute() if hasattr(self, "pck_computer") else {}
+        metrics["loss"] = torch.nanmean(torch.stack(self._val_losses).float()).item() if self._val_losses else float("nan")
+        return metrics

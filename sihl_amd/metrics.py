@@ -1,4 +1,4 @@
-"""COCO-protocol mean average precision for boxes (the metric the reference's ObjectDetection validation reports through
+"""COCO-protocol mean average precision for boxes and masks, PCK, segmentation confusion counts (box mAP: the metric the reference's ObjectDetection validation reports through
 torchmetrics' MeanAveragePrecision with the faster_coco_eval backend, src/sihl/heads/object_detection.py:219-250).
 
 Neither torchmetrics nor a COCO evaluator is available offline, so the published COCO detection-evaluation protocol is
@@ -42,23 +42,33 @@ class BoxMeanAveragePrecision:
         def np_(t):
             return t.detach().float().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t, dtype=np.float64)
         for p, t in zip(preds, targets):
-            self._images.append({"scores": np_(p["scores"]).reshape(-1), "labels": np_(p["labels"]).reshape(-1).astype(np.int64),
-                                 "boxes": np_(p["boxes"]).reshape(-1, 4), "gt_labels": np_(t["labels"]).reshape(-1).astype(np.int64),
-                                 "gt_boxes": np_(t["boxes"]).reshape(-1, 4)})
+            det, gt = np_(p["boxes"]).reshape(-1, 4), np_(t["boxes"]).reshape(-1, 4)
+            self._store(np_(p["scores"]), np_(p["labels"]), np_(t["labels"]), _iou_matrix(det, gt),
+                        (det[:, 2] - det[:, 0]) * (det[:, 3] - det[:, 1]), (gt[:, 2] - gt[:, 0]) * (gt[:, 3] - gt[:, 1]))
+
+    def _store(self, scores, labels, gt_labels, ious, det_area, gt_area) -> None:
+        """One image: detection scores / labels (n,), ground-truth labels (g,), the (n, g) IoU matrix and both area vectors -
+        everything the COCO protocol needs, whatever the geometry (boxes here, masks in MaskMeanAveragePrecision)."""
+        self._images.append({"scores": np.asarray(scores, dtype=np.float64).reshape(-1),
+                             "labels": np.asarray(labels).reshape(-1).astype(np.int64),
+                             "gt_labels": np.asarray(gt_labels).reshape(-1).astype(np.int64),
+                             "ious": np.asarray(ious, dtype=np.float64).reshape(np.asarray(scores).size, np.asarray(gt_labels).size),
+                             "det_area": np.asarray(det_area, dtype=np.float64).reshape(-1),
+                             "gt_area": np.asarray(gt_area, dtype=np.float64).reshape(-1)})
 
     # ------------------------------------------------------------------ COCO evaluate + accumulate
     def _evaluate_image(self, img, cls: int, area, max_det: int):
-        gt = img["gt_boxes"][img["gt_labels"] == cls]
-        sel = img["labels"] == cls
-        det, score = img["boxes"][sel], img["scores"][sel]
+        g_idx = np.nonzero(img["gt_labels"] == cls)[0]
+        d_idx = np.nonzero(img["labels"] == cls)[0]
+        score = img["scores"][d_idx]
         order = np.argsort(-score, kind="mergesort")[:max_det]
-        det, score = det[order], score[order]
-        g_area = (gt[:, 2] - gt[:, 0]) * (gt[:, 3] - gt[:, 1]) if len(gt) else np.zeros(0)
+        d_idx, score = d_idx[order], score[order]
+        g_area = img["gt_area"][g_idx]
         g_ignore = (g_area < area[0]) | (g_area > area[1])
         g_order = np.argsort(g_ignore, kind="mergesort")  # evaluated ground truths first
-        gt, g_ignore = gt[g_order], g_ignore[g_order]
-        ious = _iou_matrix(det, gt)
-        T, D, G = len(IOU_THRESHOLDS), len(det), len(gt)
+        g_idx, g_ignore = g_idx[g_order], g_ignore[g_order]
+        ious = img["ious"][np.ix_(d_idx, g_idx)] if len(d_idx) and len(g_idx) else np.zeros((len(d_idx), len(g_idx)))
+        T, D, G = len(IOU_THRESHOLDS), len(d_idx), len(g_idx)
         d_match = np.zeros((T, D), dtype=bool)
         d_ignore = np.zeros((T, D), dtype=bool)
         for ti, thr in enumerate(IOU_THRESHOLDS):
@@ -77,7 +87,7 @@ class BoxMeanAveragePrecision:
                     g_taken[m] = True
                     d_match[ti, di] = True
                     d_ignore[ti, di] = g_ignore[m]
-        d_area = (det[:, 2] - det[:, 0]) * (det[:, 3] - det[:, 1]) if D else np.zeros(0)
+        d_area = img["det_area"][d_idx]
         outside = (d_area < area[0]) | (d_area > area[1])
         d_ignore = d_ignore | (~d_match & outside[None, :])  # unmatched detections outside the range do not count
         return score, d_match, d_ignore, int((~g_ignore).sum())
@@ -130,6 +140,75 @@ class BoxMeanAveragePrecision:
             _, r = self._accumulate("all", m)
             out[f"mar_{m}"] = mean_valid(r)
         return out
+
+
+class MaskMeanAveragePrecision(BoxMeanAveragePrecision):
+    """The same COCO protocol with ``iou_type="segm"`` (the reference's InstanceSegmentation validation,
+    src/sihl/heads/instance_segmentation.py:299-330): IoU between boolean masks, areas = mask pixel counts.  The (n, g) IoU
+    matrix of an image is computed ON THE DEVICE at update time - one matrix product of the flattened masks - so the masks
+    themselves (100 x H x W per image) never travel to the host.  "parity unpinned" like the box metric."""
+
+    def update(self, preds: List[Dict[str, torch.Tensor]], targets: List[Dict[str, torch.Tensor]]) -> None:
+        """preds: per image {"scores" (n,), "labels" (n,), "masks" (n, H, W) bool}; targets: {"labels" (g,), "masks" (g, H, W)}."""
+        for p, t in zip(preds, targets):
+            dm, gm = p["masks"], t["masks"]
+            dm = dm.reshape(dm.shape[0], dm[0].numel() if dm.shape[0] else 0).to(torch.float32)
+            gm = gm.reshape(gm.shape[0], gm[0].numel() if gm.shape[0] else 0).to(device=dm.device, dtype=torch.float32)
+            d_area, g_area = dm.sum(1).double(), gm.sum(1).double()
+            inter = (dm @ gm.t()).double() if dm.shape[0] and gm.shape[0] else torch.zeros((dm.shape[0], gm.shape[0]), dtype=torch.float64)
+            union = (d_area[:, None] + g_area[None, :] - inter).clamp(min=1e-12) if inter.numel() else inter
+            ious = inter / union if inter.numel() else inter
+            self._store(p["scores"].detach().float().cpu().numpy(), p["labels"].detach().cpu().numpy(),
+                        t["labels"].detach().cpu().numpy(), ious.cpu().numpy(), d_area.cpu().numpy(), g_area.cpu().numpy())
+
+
+class PercentageOfCorrectKeypoints:
+    """PCK as the reference's KeypointDetection validation computes it (src/sihl/utils/pck.py:8-181, a torchmetrics
+    ``Metric`` there): per image, predictions and ground truths are paired GREEDILY by the mean distance over the keypoints
+    visible in both (lowest cost first, each used once; pairs without a mutually visible keypoint never match); for every
+    pair, the ground truth's visible keypoints count as correct when the prediction lies within ``threshold`` (coordinates
+    are image fractions); visible keypoints of unmatched ground truths count as missed.  The two counters live on the
+    device; the cost matrix is one broadcast, the greedy loop runs on its (n, g) host copy."""
+
+    def __init__(self, threshold: float = 0.05) -> None:
+        self.threshold = float(threshold)
+        self.reset()
+
+    def reset(self) -> None:
+        self.correct, self.total = 0, 0
+
+    def update(self, pred_keypoints: torch.Tensor, pred_presence: torch.Tensor, gt_keypoints: torch.Tensor,
+               gt_presence: torch.Tensor) -> None:
+        """(n, K, 2), (n, K), (g, K, 2), (g, K)."""
+        n, g = pred_keypoints.shape[0], gt_keypoints.shape[0]
+        gt_vis = gt_presence.to(pred_keypoints.device) > 0
+        if n == 0 or g == 0:
+            self.total += int(gt_vis.sum()) if g else 0
+            return
+        gt_keypoints = gt_keypoints.to(pred_keypoints.device)
+        dist = (pred_keypoints[:, None].float() - gt_keypoints[None].float()).norm(dim=-1)  # (n, g, K)
+        mutual = (pred_presence > 0)[:, None, :] & gt_vis[None, :, :]
+        cnt = mutual.sum(-1)
+        cost = torch.where(cnt > 0, (dist * mutual).sum(-1) / cnt.clamp(min=1), torch.full_like(dist[..., 0], float("inf")))
+        cost_h = cost.double().cpu().numpy().copy()
+        within = ((dist <= self.threshold) & gt_vis[None]).sum(-1).cpu().numpy()  # correct keypoints of every (pred, gt) pair
+        vis_h = gt_vis.sum(-1).cpu().numpy()
+        matched = np.zeros(g, dtype=bool)
+        while True:
+            flat = int(np.argmin(cost_h))  # first minimum in row-major order, as `nonzero()[0]` in the reference
+            i, j = divmod(flat, g)
+            if not np.isfinite(cost_h[i, j]):
+                break
+            matched[j] = True
+            if vis_h[j] > 0:
+                self.correct += int(within[i, j])
+                self.total += int(vis_h[j])
+            cost_h[i, :] = np.inf
+            cost_h[:, j] = np.inf
+        self.total += int(vis_h[~matched].sum())
+
+    def compute(self) -> Dict[str, float]:
+        return {"PCK": (self.correct / self.total) if self.total else 0.0}
 
 
 class SegmentationConfusion:

@@ -315,3 +315,39 @@ def test_eval_after_graph_replays_sees_the_trained_weights(amp):
         if prev is not None:  # the second validation is NOT the first one again (lr 1e-3 moves the scores visibly)
             assert float((a[1] - prev[1]).abs().max()) > 0 and float((b[1] - prev[1]).abs().max()) > 0
         prev = b
+
+
+def test_sibling_heads_report_their_validation_metrics():
+    """InstanceSegmentation / KeypointDetection validation (reference instance_segmentation.py:299-330,
+    keypoint_detection.py:320-350): loss + COCO-protocol mask mAP / PCK@0.05, accumulated over two steps; the metric
+    arithmetic itself is hand-checked on the CPU (tests/test_host_cpu.py)."""
+    import sihl_amd
+    chans = [3, 8, 16, 32, 32, 32]
+    g = torch.Generator().manual_seed(2)
+    feats = [torch.rand(2, 3, 128, 128, generator=g).cuda()] + [torch.randn(2, c, 128 // 2 ** l, 128 // 2 ** l, generator=g).cuda()
+                                                                 for l, c in enumerate(chans) if l > 0]
+    torch.manual_seed(0)
+    iseg = sihl_amd.heads.InstanceSegmentation(chans, num_classes=3, num_channels=32, max_instances=20).cuda().eval()
+    masks = [torch.zeros(2, 128, 128, dtype=torch.bool), torch.zeros(1, 128, 128, dtype=torch.bool)]
+    masks[0][0, 10:60, 20:70] = True
+    masks[0][1, 70:120, 50:110] = True
+    masks[1][0, 30:100, 30:100] = True
+    classes = [torch.tensor([0, 2]), torch.tensor([1])]
+    iseg.on_validation_start()
+    for _ in range(2):
+        loss, _ = iseg.validation_step(feats, [c.cuda() for c in classes], [m.cuda() for m in masks])
+        assert torch.isfinite(loss)
+    out = iseg.on_validation_end()
+    assert {"map", "map_50", "map_75", "mar_1", "mar_10", "mar_20", "loss"} <= set(out) and -1.0 <= out["map"] <= 1.0
+
+    kpt = sihl_amd.heads.KeypointDetection(chans, num_keypoints=4, num_channels=32, max_instances=10).cuda().eval()  # 16 positions at level 5
+    keypoints = [torch.tensor([[[20., 20], [40, 30], [60, 50], [30, 70]], [[80., 90], [100, 100], [90, 110], [70, 120]]]),
+                 torch.tensor([[[64., 64], [70, 60], [50, 80], [90, 40]]])]
+    presence = [torch.tensor([[True, True, True, False], [True, True, True, True]]), torch.tensor([[True, False, True, True]])]
+    kpt.on_validation_start()
+    for _ in range(2):
+        loss, _ = kpt.validation_step(feats, [k.cuda() for k in keypoints], [p.cuda() for p in presence])
+        assert torch.isfinite(loss)
+    out = kpt.on_validation_end()
+    assert set(out) == {"PCK", "loss"} and 0.0 <= out["PCK"] <= 1.0
+    assert kpt.pck_computer.total == 2 * 10  # every visible ground-truth keypoint is counted once per step, matched or not

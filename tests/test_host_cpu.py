@@ -270,3 +270,45 @@ def test_averager_without_trainable_parameters_does_not_raise():
     avg = GradientAverager([torch.zeros(3)], force=False)
     avg.active, avg.buckets = True, []  # an active averager with nothing to average (all parameters frozen)
     avg.finish()
+
+
+def test_mask_map_and_pck_hand_cases():
+    """Mask mAP (COCO protocol on mask IoU, sihl_amd/metrics.py) and PCK (reference utils/pck.py restated) on cases worked out by
+    hand.  Masks: on a 10x10 canvas, ground truth = rows 0-4 (50 px); detection A = rows 0-4 -> IoU 1; detection B = rows
+    0-2 (30 px) -> IoU 0.6 (a true positive at thresholds 0.50-0.60: 3 of 10)."""
+    from sihl_amd.metrics import MaskMeanAveragePrecision, PercentageOfCorrectKeypoints
+
+    def rows(a, b):
+        m = torch.zeros(10, 10, dtype=torch.bool)
+        m[a:b] = True
+        return m
+
+    m = MaskMeanAveragePrecision((1, 10, 100))
+    gt = [{"labels": torch.tensor([0]), "masks": rows(0, 5)[None]}]
+    m.update([{"scores": torch.tensor([0.9]), "labels": torch.tensor([0]), "masks": rows(0, 5)[None]}], gt)
+    assert m.compute()["map"] == 1.0
+    m.reset()
+    m.update([{"scores": torch.tensor([0.5]), "labels": torch.tensor([0]), "masks": rows(0, 3)[None]}], gt)
+    r = m.compute()
+    assert abs(r["map"] - 0.3) < 1e-9 and r["map_50"] == 1.0 and r["map_75"] == 0.0
+    assert r["map_small"] >= 0 and r["map_large"] == -1.0  # a 50-pixel mask is "small" (< 32^2)
+    m.reset()  # an image without detections and one without ground truth
+    m.update([{"scores": torch.zeros(0), "labels": torch.zeros(0, dtype=torch.int64), "masks": torch.zeros(0, 10, 10, dtype=torch.bool)},
+              {"scores": torch.tensor([0.3]), "labels": torch.tensor([0]), "masks": rows(5, 9)[None]}],
+             [gt[0], {"labels": torch.zeros(0, dtype=torch.int64), "masks": torch.zeros(0, 10, 10, dtype=torch.bool)}])
+    assert m.compute()["map"] == 0.0
+
+    # PCK@0.05: two ground truths with 3 keypoints (the third of gt 1 invisible), three predictions.
+    gt_k = torch.tensor([[[0.10, 0.10], [0.20, 0.20], [0.30, 0.30]], [[0.60, 0.60], [0.70, 0.70], [0.80, 0.80]]])
+    gt_v = torch.tensor([[1, 1, 1], [1, 1, 0]])
+    pred = torch.tensor([[[0.61, 0.60], [0.70, 0.79], [0.0, 0.0]],     # pairs with gt 1: kp0 within 0.05, kp1 off by 0.09, kp2 not counted
+                         [[0.10, 0.12], [0.20, 0.20], [0.33, 0.30]],   # pairs with gt 0: all three within 0.05
+                         [[0.90, 0.90], [0.90, 0.90], [0.90, 0.90]]])  # left over
+    pck = PercentageOfCorrectKeypoints(0.05)
+    pck.update(pred, torch.ones(3, 3), gt_k, gt_v)
+    assert pck.correct == 4 and pck.total == 5 and abs(pck.compute()["PCK"] - 0.8) < 1e-12
+    pck.update(pred[:0], torch.ones(0, 3), gt_k, gt_v)  # no predictions: every visible ground-truth keypoint is missed
+    assert pck.correct == 4 and pck.total == 10
+    pck.update(pred[:1], torch.ones(1, 3), gt_k, gt_v)  # one prediction, two ground truths: gt 0's three keypoints missed
+    assert pck.correct == 5 and pck.total == 15
+    assert PercentageOfCorrectKeypoints().compute()["PCK"] == 0.0
