@@ -18,6 +18,8 @@ _ACT_MODULES = {
     "relu": lambda: nn.ReLU(inplace=True),
     "silu": lambda: nn.SiLU(inplace=True),
     "sigmoid": nn.Sigmoid,
+    "softplus": nn.Softplus,
+    "softmax": lambda: nn.Softmax(dim=1),
 }
 
 
@@ -48,8 +50,6 @@ class _ConvBlock(nn.Sequential):
             conv, bn = self._parts()
             if conv.groups != 1 or conv.padding_mode != "zeros":
                 raise NotImplementedError("sihl_amd conv kernels cover groups=1, zero padding")
-            if any(isinstance(m, (nn.GroupNorm, nn.Softplus, nn.Softmax)) for m in self):
-                raise NotImplementedError("GroupNorm / softplus / softmax blocks are outside the HIP hot path")
             (sh, sw), (ph, pw), (dh, dw) = conv.stride, conv.padding, conv.dilation
             if sh != sw or ph != pw or dh != dw:
                 raise NotImplementedError("square stride / padding / dilation only")
@@ -77,8 +77,18 @@ class _ConvBlock(nn.Sequential):
                                pad=ph, dil=dh, act=self.act, order=self.order, training=self.training, eps=bn.eps,
                                momentum=bn.momentum, defer=defer if cout % vec == 0 else None)
         else:
-            y = ops.conv_block(x, weight, bias, None, None, None, None, stride=sh, pad=ph, dil=dh, act=self.act)
-        return y if y.shape[-1] == cout else y[..., :cout]
+            fused_act = self.act if self.act in (None, "relu", "silu", "sigmoid") else None
+            y = ops.conv_block(x, weight, bias, None, None, None, None, stride=sh, pad=ph, dil=dh, act=fused_act)
+        y = y if y.shape[-1] == cout else y[..., :cout]
+        tail = [m for m in list(self)[1:] if isinstance(m, (nn.GroupNorm, nn.Softplus, nn.Softmax))]
+        if tail:
+            # the reference's rarer block variants (convblocks.py:76-85: softplus / softmax(dim=1) activations, GroupNorm):
+            # the conv (+ bias) runs on the HIP kernel, these modules as device ops on the NCHW view of its output
+            v = ops.nchw_view(y)
+            for m in tail:
+                v = m(v)
+            y = ops.nhwc(v)
+        return y
 
     def forward_fused_node(self, fuse, defer=None) -> Optional[Tensor]:
         """This block applied to a BiFPN fusion node, node and conv in ONE launch (ops.fused_node_conv_block; fuse = ("up2", a,
@@ -150,12 +160,14 @@ class ConvNormAct(_ConvBlock):
                                            groups=groups, bias=use_bias)]
         if act is not None:
             if act not in _ACT_MODULES:
-                raise NotImplementedError(f"activation {act!r} is outside the HIP hot path")
+                raise ValueError(f"unknown activation {act!r}")
             mods.append(_ACT_MODULES[act]())
         if norm == "batch":
             mods.append(nn.BatchNorm2d(out_channels))
+        elif norm == "group":
+            mods.append(nn.GroupNorm(in_channels // 8, out_channels))  # (the reference's group count, convblocks.py:85)
         elif norm is not None:
-            raise NotImplementedError(f"norm {norm!r} is outside the HIP hot path")
+            raise ValueError(f"unknown norm {norm!r}")
         super().__init__(*mods)
         self.act = act
 

@@ -1096,3 +1096,29 @@ def test_bifpn_eval_emitted_nodes_match_separate_launches():
     # and the emit path really ran: fewer launches than the separate form is checked by the profiler in bench runs; here the
     # kernel must at least report the shapes as supported
     assert ops.pyr_conv_supported(3, 16, 64, 64, 0, torch.bfloat16)
+
+
+@pytest.mark.parametrize("kw", [dict(norm="group", act="relu"), dict(norm="group", act="silu"), dict(norm=None, act="softplus"),
+                                dict(norm=None, act="softmax"), dict(norm="group", act=None, kernel_size=1)])
+def test_conv_norm_act_rarer_variants_match_oracle(kw):
+    """ConvNormAct with GroupNorm (in_channels // 8 groups) and the softplus / softmax(dim=1) activations (reference
+    layers/convblocks.py:76-85): conv on the HIP kernel, the rest as device ops - forward, input and parameter gradients in
+    fp32 against the CPU oracle block with the same state_dict."""
+    import oracle
+    import sihl_amd
+    torch.manual_seed(7)
+    o = oracle.ConvNormAct(32, 48, **kw)
+    h = sihl_amd.layers.ConvNormAct(32, 48, **kw)
+    assert list(h.state_dict()) == list(o.state_dict())
+    h.load_state_dict(o.state_dict())
+    h = h.cuda()
+    x = torch.randn(3, 32, 12, 10)
+    xo, xh = x.clone().requires_grad_(True), x.clone().cuda().requires_grad_(True)
+    yo, yh = o(xo), h(xh)
+    cot = torch.randn_like(yo)
+    yo.backward(cot)
+    yh.backward(cot.cuda())
+    torch.testing.assert_close(yh.cpu(), yo, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(xh.grad.cpu(), xo.grad, rtol=1e-4, atol=1e-4 * float(xo.grad.abs().max()))
+    for (n, po), ph in zip(o.named_parameters(), h.parameters()):
+        torch.testing.assert_close(ph.grad.cpu(), po.grad, rtol=1e-3, atol=1e-4 * max(1.0, float(po.grad.abs().max())), msg=lambda s: f"{n}: {s}")
