@@ -95,6 +95,7 @@ int sihl_conv2d_dgrad_add(const void* dout, const void* wt_t, void* din, const v
 int sihl_conv2d_splitk_enable(int on); /* tuning / test hook */
 int sihl_conv2d_small_enable(int on);  /* test hook: kernel of the 3x3 convs on the small pyramid levels - 1 (default) csrc/conv_pyr.hip where its shapes allow, else csrc/conv_small.hip; 2 = conv_small.hip only; 0 = the general tile kernel */
 int sihl_conv2d_small_mode(void);      /* the current value of that hook */
+int sihl_conv2d_halo_enable(int mode); /* test hook: csrc/conv_halo.hip (3x3 on 64-wide maps, 256 x 256 tile, input patch resident in LDS) - 1 (default) where its grid fills the chip, 2 wherever the shape allows, 0 off */
 int sihl_conv2d_rules_off(int mask);   /* TUNING builds only: disable individual dispatch rules */
 int sihl_conv2d_krot(int n);           /* TUNING builds only: stage stride between neighbouring workgroups' K-loop starts (100000 * log2(group) + 1000 * min_stages + stride; default 200013 = groups of 4 workgroups share a start, stride 13; 0 = lockstep) */
 

@@ -47,6 +47,7 @@ SIGNATURES = {
     "sihl_conv2d_splitk_enable": (I, [I]),
     "sihl_conv2d_small_enable": (I, [I]),
     "sihl_conv2d_small_mode": (I, []),
+    "sihl_conv2d_halo_enable": (I, [I]),
     "sihl_conv2d_rules_off": (I, [I]),
     "sihl_conv2d_krot": (I, [I]),
     "sihl_conv2d_wgrad_force_register_staging": (I, [I]),

@@ -65,6 +65,10 @@ int sihl_conv2d_rules_off(int mask) { SIHL_TUNING_SET(g_rules_off, mask); }
 int sihl_conv2d_small_enable(int on) { sihl_small_set_enabled(on != 0); sihl_pyr_set_mode(on); return 0; }
 int sihl_conv2d_small_mode(void) { return sihl_pyr_get_mode(); }
 
+// Test hook: the halo-resident 256 x 256 tile of 3x3 convs on 64-wide maps (conv_halo.hip) - 1 (default) = where its grid fills
+// the chip, 2 = wherever the shape allows (small batches in tests), 0 = off (the general tile).  Both stay parity-tested.
+int sihl_conv2d_halo_enable(int mode) { sihl_halo_set_mode(mode); return 0; }
+
 // Tuning hook: 100000 * log2(group) + 1000 * min_stages + stride - the stage stride between the K-loop starts of
 // neighbouring GROUPS of workgroups (default 200013: groups of 4 share a start and with it their L2 fills, stride 13;
 // 0 = lockstep).

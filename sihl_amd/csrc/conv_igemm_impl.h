@@ -1067,6 +1067,8 @@ int dispatch(const ConvParams& p, hipStream_t stream) {
     // 3x3 convs of the small pyramid levels: halo-resident input patch, split-K finished inside the launch (conv_small.hip)
     if (dma && g_tile_override == 0 && !g_nbuf && sihl_pyr_eligible(p)) return sihl_pyr_launch(p, stream);
     if (dma && g_tile_override == 0 && !g_nbuf && sihl_small_eligible(p)) return sihl_small_launch(p, stream);
+    // 3x3, 256 -> 256 channels on 64-wide maps: the 256 x 256 tile with the input patch resident in LDS (conv_halo.hip)
+    if (dma && g_tile_override == 0 && !g_nbuf && sihl_halo_eligible(p)) return sihl_halo_launch(p, stream);
   }
   if (!dma) {
     if (p.Cout > 128) return launch_reg<T, 256, 2, 2>(p, stream);

@@ -54,5 +54,9 @@ bool sihl_pyr_eligible(const ConvParams& p);
 int sihl_pyr_launch(const ConvParams& p, hipStream_t stream);
 void sihl_pyr_set_mode(int mode);
 int sihl_pyr_get_mode();
+// conv_halo.hip: 256 x 256 tile with a halo-resident input patch for 3x3 convs on 64-wide maps (bf16)
+bool sihl_halo_eligible(const ConvParams& p);
+int sihl_halo_launch(const ConvParams& p, hipStream_t stream);
+void sihl_halo_set_mode(int mode);
 // conv_igemm_bf16.hip: the finishing launch of a split-K conv (sums the fp32 slices, runs the epilogue), for conv_small.hip
 int sihl_conv_splitk_finish_bf16(const ConvParams& p, hipStream_t stream);

@@ -1122,3 +1122,57 @@ def test_conv_norm_act_rarer_variants_match_oracle(kw):
     torch.testing.assert_close(xh.grad.cpu(), xo.grad, rtol=1e-4, atol=1e-4 * float(xo.grad.abs().max()))
     for (n, po), ph in zip(o.named_parameters(), h.parameters()):
         torch.testing.assert_close(ph.grad.cpu(), po.grad, rtol=1e-3, atol=1e-4 * max(1.0, float(po.grad.abs().max())), msg=lambda s: f"{n}: {s}")
+
+
+@pytest.mark.parametrize("mode", ["eval", "train_act_norm", "train_norm_act", "bias_silu", "plain"])
+@pytest.mark.parametrize("shape", [(2, 64, 256, 256), (1, 8, 64, 256), (3, 12, 96, 512), (1, 4, 32, 256), (2, 32, 256, 256, 32),
+                                   (3, 8, 64, 512, 32)])
+def test_conv_halo_tile(shape, mode):
+    """conv_halo.hip - 3x3 convs on 64-wide maps on the 256 x 256 tile with the input patch resident in LDS (24 stages of one
+    kernel row x 32 channels) - against the general tile on the same operands (same bf16 operands, fp32 sums in another order)
+    and an fp32 PyTorch conv, for every epilogue of the conv blocks; tiles at the top / bottom image border and between
+    images (H = 4 .. 64), one to eight channel chunks, two out-channel tiles; run-to-run bit-identity."""
+    from sihl_amd import _C, ops
+    N, H, Cin, Cout = shape[:4]
+    W = shape[4] if len(shape) > 4 else 64  # (32-wide maps: the 128-pixel tile on 8 waves)
+    g = torch.Generator(device="cuda").manual_seed(N * 1000 + H * 10 + Cin)
+    x = torch.randn(N, H, W, Cin, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) * (9 * Cin) ** -0.5).bfloat16()
+    bias = torch.randn(Cout, device="cuda", generator=g)
+    sc, sh = torch.rand(Cout, device="cuda", generator=g) + 0.5, torch.randn(Cout, device="cuda", generator=g)
+    kw = {"eval": dict(act="relu", post=(sc, sh)), "train_act_norm": dict(act="relu", stats_mode=2),
+          "train_norm_act": dict(stats_mode=1), "bias_silu": dict(bias=bias, act="silu", pre=(sc, sh)), "plain": {}}[mode]
+    bias_arg = kw.pop("bias", None)
+    lib = _C.lib()
+    run = lambda: ops.conv2d_raw(x, w, bias_arg, 1, 1, 1, **kw)  # noqa: E731
+    try:
+        lib.sihl_conv2d_halo_enable(0)
+        y0, s0 = run()
+        lib.sihl_conv2d_halo_enable(2)
+        y1, s1 = run()
+        for _ in range(10):
+            y2, s2 = run()
+            assert torch.equal(y2.view(torch.int16), y1.view(torch.int16)) and (s1 is None or torch.equal(s2, s1))
+        lib.sihl_conv2d_halo_enable(3)  # the plain loop form: same stages in the same order, hence the same bits
+        y3, s3 = run()
+        assert torch.equal(y3.view(torch.int16), y1.view(torch.int16)) and (s1 is None or torch.equal(s3, s1))
+    finally:
+        lib.sihl_conv2d_halo_enable(1)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias_arg, padding=1).permute(0, 2, 3, 1)
+    pre = ref
+    if "pre" in kw:
+        ref = ref * sc + sh
+    ref = {"relu": torch.relu, "silu": F.silu}.get(kw.get("act"), lambda t: t)(ref)
+    stat_src = pre if kw.get("stats_mode") == 1 else ref
+    if "post" in kw:
+        ref = ref * sc + sh
+    scale = float(ref.abs().max())
+    torch.testing.assert_close(y1.float(), ref, rtol=2e-2, atol=2e-2 * scale)
+    torch.testing.assert_close(y1.float(), y0.float(), rtol=1e-2, atol=1e-2 * scale)
+    assert float((y1.float() - y0.float()).abs().mean()) < 1e-3 * scale
+    if kw.get("stats_mode"):
+        rows = N * H * W // 128
+        assert s1.shape == (rows, 2, Cout)
+        src = stat_src.reshape(rows, 128, Cout)
+        torch.testing.assert_close(s1[:, 0], src.sum(1), rtol=1e-3, atol=1e-3 * float(src.abs().sum(1).max()))
+        torch.testing.assert_close(s1, s0, rtol=1e-4, atol=1e-4 * float(s0.abs().max()))

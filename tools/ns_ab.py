@@ -19,7 +19,8 @@ prep = ops.PreparedWeights(model, torch.bfloat16)
 lib = _C.lib()
 
 
-def variant(small, mlp, waves=4):
+def variant(small, mlp, waves=4, halo=1):
+    lib.sihl_conv2d_halo_enable(halo)
     lib.sihl_conv2d_small_enable(small)
     lib.sihl_mlp_rows_config(waves)
     ops.MLP_KERNEL = mlp
@@ -30,7 +31,8 @@ def variant(small, mlp, waves=4):
 VARIANTS = [("default (conv_pyr on P5-P7, register MLP)", 1, "rows"),
             ("conv_small on P5-P7 (round-3 kernel)", 2, "rows"),
             ("general conv on P5-P7", 0, "rows"), ("LDS-tile MLP", 1, "tile"),
-            ("register MLP as one 8-wave workgroup per CU, 4-stage ring", 1, "rows", 8)]
+            ("register MLP as one 8-wave workgroup per CU, 4-stage ring", 1, "rows", 8),
+            ("P3 3x3 on the general 256x256 tile (no halo-resident patch)", 1, "rows", 4, 0)]
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 res = {v[0]: [] for v in VARIANTS}
 for rnd in range(rounds):
