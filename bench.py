@@ -518,15 +518,15 @@ def main():
         pmc_all = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
         # every kernel family the profiler's conv slot times: the tile kernel, the small-level kernel and the split-K
         # finishing launch (one profiled "launch" = one conv call); per-launch traffic = their HBM bytes per step / calls per step
-        fam = [pmc_all["kernels"][k] for k in ("conv_igemm_dma_kernel", "conv_igemm_kernel", "conv_small_kernel",
-                                                "conv_splitk_epilogue_kernel") if k in pmc_all["kernels"]]
+        fam = [pmc_all["kernels"][k] for k in ("conv_igemm_dma_kernel", "conv_igemm_kernel", "conv_small_kernel", "conv_pyr_kernel",
+                                                "conv_halo_kernel", "conv_splitk_epilogue_kernel") if k in pmc_all["kernels"]]
         pmc_total_mb = sum(f["traffic_MB_per_launch"] * f["launches_per_step"] for f in fam)
         if pmc_all.get("source_stamp") != source_stamp():
             traffic_note = (f"profiles/{pmc_name} was measured on other kernel sources (stamp "
                             f"{pmc_all.get('source_stamp')} != {source_stamp()}): stale, not reported")
         elif args.dtype == "bf16" and args.batch == 32 and args.size == 512:
             traffic = pmc_total_mb * 1e6 / (n.value / profiled_steps) if n.value else None
-            traffic_note = ("HBM bytes per conv call (FETCH_SIZE x2 + WRITE_SIZE of the tile, small-level and split-K finishing "
+            traffic_note = ("HBM bytes per conv call (FETCH_SIZE x2 + WRITE_SIZE of the tile, halo, pyramid-top and split-K finishing "
                             "kernels per step / conv calls per step; separate rocprofv3 --pmc passes over this "
                             f"command, profiles/{pmc_name}, same source stamp); algorithmic bytes per launch: "
                             "avg_algorithmic_mb_per_launch")
@@ -534,7 +534,7 @@ def main():
         pass
     if n.value:
         achieved = fl.value / (ms.value * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (NHWC implicit-GEMM conv: fwd / dgrad / linear)",
+        roofline = {"bound": "mfma", "kernel": "NHWC implicit-GEMM conv on the matrix cores: fwd / dgrad / linear (conv_igemm_dma_kernel tiles, conv_halo_kernel on 64- / 32-wide maps, conv_pyr_kernel on the pyramid's top levels)",
                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                     "traffic_note": traffic_note,
                     "avg_algorithmic_mb_per_launch": by.value / n.value / 1e6,

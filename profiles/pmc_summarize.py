@@ -33,6 +33,7 @@ def family(n):
                 "conv_wgrad_kernel", "wgrad_reduce_kernel", "norm_bwd_apply_kernel", "norm_bwd_reduce_kernel",
                 "affine_act_bwd_kernel", "affine_act_kernel", "layernorm_act_bwd_kernel", "layernorm_act_kernel",
                 "weight_prepare_t_kernel", "weight_prepare_kernel", "conv_splitk_epilogue_kernel", "conv_small_kernel",
+                "conv_pyr_kernel", "conv_halo_kernel", "wgrad_reduce_small_kernel", "bn_finalize_kernel", "colsum_finalize_kernel",
                 "mlp_rows_kernel", "blur_fuse_kernel", "fuse_up2_kernel"):
         if key in n:
             return key

@@ -24,7 +24,7 @@ def cat(n):
     mine = ("conv_igemm", "conv_wgrad", "colsum", "norm_bwd", "affine_act", "layernorm", "fuse_", "blur_", "up2_",
             "bn_finalize", "bn_eval", "weight_flip", "wgrad_reduce", "topk", "gather_rows", "od_", "fusion_wgrad",
             "resize", "nearest", "uafm", "softmax_max", "ce_resize", "maxpool3x3s2", "conv_splitk", "conv_add", "weight_prepare",
-            "iseg_mask", "conv_small", "mlp_rows", "mlp_fused", "bn_stats", "od_decode", "colsum", "stem_")
+            "iseg_mask", "conv_small", "conv_pyr", "conv_halo", "mlp_rows", "mlp_fused", "bn_stats", "od_decode", "colsum", "stem_")
     if any(k in n for k in mine):
         return "sihl_hip"
     if n.startswith("MIOpen") or "igemm_" in n or "ck::" in n or "_ZN2ck" in n or "SubTensor" in n or "naive_conv" in n \

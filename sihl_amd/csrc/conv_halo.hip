@@ -60,6 +60,10 @@ __global__ __launch_bounds__((BM / 64 * 4 * 64), (BM / 64)) void conv_halo_kerne
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   const int tid = threadIdx.x, lane = tid & 63;
+#ifdef SIHL_HALO_STAMPS
+  unsigned long long t_entry = 0;
+  HALO_T(t_entry);
+#endif
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int l16 = lane & 15, g = lane >> 4;
@@ -260,6 +264,16 @@ __global__ __launch_bounds__((BM / 64 * 4 * 64), (BM / 64)) void conv_halo_kerne
 #endif
   __syncthreads();  // everyone is done reading the last stage: LDS is free for the epilogue's transpose
   conv_epilogue<bf16_t, BM, HBN, WM, WN, TILE>(p, acc, smem, tile_m, m0, n0);
+#ifdef SIHL_HALO_STAMPS
+  {
+    unsigned long long t_end;
+    HALO_T(t_end);
+    if (p.partial && blockIdx.x == 0 && lane == 0) {
+      unsigned long long* o = (unsigned long long*)p.partial + 64 + wave * 2;
+      o[0] = t_start - t_entry; o[1] = t_end - t3;  // prologue (entry -> K loop), epilogue (K loop end -> stores issued)
+    }
+  }
+#endif
 }
 
 // test hook (sihl_conv2d_halo_enable): 0 = off, 1 = where the grid fills the chip, 2 = wherever the shape allows, 3 = as 2 with

@@ -29,6 +29,8 @@ for mode, name in ((3, "barrier in front of the stage"), (2, "barrier before the
     tot = sum(r[0] for r in t) / 16
     print(f"{name}: K loop {tot:.0f} cycles per wave (24 stages: {tot / 24:.0f} per stage, 3 072 of them matrix cycles of the SIMD)")
     print("   wave: total | own DMA wait | barrier wait | multiply + issue")
+    pe = ws[64:96].cpu().reshape(16, 2).tolist()
+    print(f"   prologue (entry -> K loop) {sum(r[0] for r in pe) / 16:.0f} cycles, epilogue (K loop end -> stores issued) {sum(r[1] for r in pe) / 16:.0f} cycles")
     for wv in (0, 3, 7, 8, 12, 15):
         r = t[wv]
         print(f"   {wv:4d}: {r[0]:6d} | {r[1]:6d} ({100 * r[1] / r[0]:4.1f} %) | {r[2]:6d} ({100 * r[2] / r[0]:4.1f} %) | {r[3]:6d} ({100 * r[3] / r[0]:4.1f} %)")

@@ -12,7 +12,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob('/tmp/pmc_*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name']
-        k = 'conv_igemm_dma' if 'conv_igemm_dma' in n else 'conv_wgrad_dma' if 'conv_wgrad_dma' in n else None
+        k = 'conv_halo' if 'conv_halo' in n else 'conv_igemm_dma' if 'conv_igemm_dma' in n else 'conv_wgrad_dma' if 'conv_wgrad_dma' in n else None
         if k:
             agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in agg.items():
