@@ -195,6 +195,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 // k-contiguous per lane, so they are read TRANSPOSED with ds_read_b64_tr_b16.  A 16-lane group of that
 // instruction touches 4 consecutive pixel rows x 64 B, which on 512-byte rows would all hit the same bank
 // window: the 64-byte block index of a row is XOR-ed with (row & 3) on the DMA source side and on the read.
+#ifdef SIHL_WGRAD_STAMPS
+__device__ unsigned long long* g_wgrad_stamps = nullptr;
+#define WG_T(x) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
 constexpr int WB = 256;        // channels per panel side
 constexpr int WKP = 64;        // pixels per stage
 constexpr int WROW = WB * 2;   // bytes per pixel row in LDS
@@ -337,13 +341,36 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_wgrad_dma_kernel(const W
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef SIHL_WGRAD_STAMPS
+    unsigned long long w_t0, w_t1, w_t2, w_t3, w_comp = 0, w_wait = 0, w_bar = 0, w_start;
+    WG_T(w_start);
+#endif
     for (int s = 0; s < nstages; ++s) {
       const bool more = s + 1 < nstages;
       const unsigned abase = lds_base + ((s + 1) & 1) * STAGE + wave * NP * 1024;
+#ifdef SIHL_WGRAD_STAMPS
+      WG_T(w_t0);
+#endif
       compute(s & 1, more, abase);
+#ifdef SIHL_WGRAD_STAMPS
+      WG_T(w_t1);
+#endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef SIHL_WGRAD_STAMPS
+      WG_T(w_t2);
+#endif
       __syncthreads();
+#ifdef SIHL_WGRAD_STAMPS
+      WG_T(w_t3);
+      w_comp += w_t1 - w_t0; w_wait += w_t2 - w_t1; w_bar += w_t3 - w_t2;
+#endif
     }
+#ifdef SIHL_WGRAD_STAMPS
+    if (g_wgrad_stamps && blockIdx.x == 0 && lane == 0) {
+      unsigned long long* o = g_wgrad_stamps + wave * 5;
+      o[0] = w_t3 - w_start; o[1] = w_comp; o[2] = w_wait; o[3] = w_bar; o[4] = (unsigned long long)nstages;
+    }
+#endif
   }
 
   const int half = lane >> 5;
@@ -671,6 +698,13 @@ int choose_splits(long M, int tiles, int kp, int target, long n_weights) {
 }  // namespace
 
 extern "C" {
+
+#ifdef SIHL_WGRAD_STAMPS
+int sihl_wgrad_stamps(void* buf) {  // diagnostic builds: device buffer of 16 x 5 u64 that workgroup 0 of the LDS-DMA kernel fills
+  unsigned long long* b = (unsigned long long*)buf;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wgrad_stamps), &b, sizeof(b));
+}
+#endif
 
 // Test hook: 1 = always use the register-staged 128x128 kernel (the fp32 / small-channel path).
 int sihl_conv2d_wgrad_force_register_staging(int on) { g_wgrad_force_reg = on != 0; return 0; }

@@ -1133,6 +1133,47 @@ class BlurFuseFn(torch.autograd.Function):
         return da, db, dc, dw, None, None, None
 
 
+class GradClipPlan:
+    """Static tables of sihl_grad_clip for one list of gradient sizes: (tensor, 64 Ki-element chunk) per workgroup, the
+    element counts, the scratch row.  Built once per model; ``run`` is three launches and no tensor creation."""
+
+    GROUP, CHUNK = 320, 1 << 16
+
+    def __init__(self, numels, device):
+        import ctypes
+
+        self.numels = tuple(int(n) for n in numels)
+        pairs, groups = [], []
+        for g0 in range(0, len(self.numels), self.GROUP):
+            before = len(pairs)
+            for k, n in enumerate(self.numels[g0:g0 + self.GROUP]):
+                pairs.extend((k, c) for c in range(max(1, -(-n // self.CHUNK))))
+            groups.append(len(pairs) - before)
+        self.nblocks = len(pairs)
+        self.map = torch.tensor(pairs, dtype=torch.int32).to(device)
+        self.numel = torch.tensor(self.numels, dtype=torch.int64).to(device)
+        self.scratch = torch.zeros(self.nblocks + 2, dtype=torch.float32, device=device)
+        self.group_blocks = (ctypes.c_int * len(groups))(*groups)
+        self.ptrs = (ctypes.c_void_p * len(self.numels))()
+
+    def run(self, grads, max_norm: float) -> Tensor:
+        """Clips ``grads`` (dense fp32 tensors of the plan's sizes) in place; returns the 2-float (coefficient, total norm)."""
+        ptrs = self.ptrs
+        for k, g in enumerate(grads):
+            ptrs[k] = g.data_ptr()
+        rc = _C.lib().sihl_grad_clip(ptrs, len(grads), _p(self.map), self.group_blocks, _p(self.numel), float(max_norm),
+                                     _p(self.scratch), self.scratch.numel(), _stream())
+        check(rc, "sihl_grad_clip")
+        return self.scratch[self.nblocks:]
+
+
+def grad_clip_supported(grads) -> bool:
+    """Dense fp32 device tensors (any memory format: norm and scale do not care about the order of elements)."""
+    return all(g.is_cuda and g.dtype == torch.float32 and not g.is_sparse and g.numel() > 0
+               and (g.is_contiguous() or g.is_contiguous(memory_format=torch.channels_last)
+                    or g.untyped_storage().nbytes() == 4 * g.numel()) for g in grads)
+
+
 class Up2Fn(torch.autograd.Function):
     """Plain bilinear x2 upsample (align_corners=False), NHWC."""
 

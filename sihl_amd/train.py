@@ -355,14 +355,27 @@ class Trainer:
         return torch.stack(losses).sum(), metrics
 
     def _clip_gradients(self) -> None:
-        """torch.nn.utils.clip_grad_norm_(parameters, max_norm) (the reference's Lightning ``gradient_clip_val``) - the same
-        multi-tensor launches in the same order (per-tensor 2-norms, the norm of their stack, coefficient clamped to 1, one
-        in-place multiply: bit-identical results), without the per-call grouping by device and dtype: ~0.5 ms of host time
-        per step on 320 parameters.  Mixed devices / dtypes take the library routine."""
+        """torch.nn.utils.clip_grad_norm_(parameters, max_norm) (the reference's Lightning ``gradient_clip_val``): the norm of
+        all gradients together, every gradient scaled by min(1, max_norm / (norm + 1e-6)).  Dense fp32 device gradients take
+        sihl_grad_clip (three launches, no per-tensor results: 2.8 ms -> 0.3 ms of host time per step on 320 parameters);
+        anything else the library's multi-tensor routines in the reference's order."""
         grads = [p.grad for p in self._params if p.grad is not None]
         if not grads:
             return
         g0 = grads[0]
+        if g0.is_cuda:
+            from sihl_amd import ops
+
+            plan = self.__dict__.get("_clip_plan")
+            sizes = tuple(g.numel() for g in grads)
+            if plan is None or plan.numels != sizes or plan.map.device != g0.device:
+                plan = ops.GradClipPlan(sizes, g0.device) if ops.grad_clip_supported(grads) else None
+                if torch.cuda.is_current_stream_capturing() and plan is not None:
+                    raise RuntimeError("gradient-clip tables must exist before graph capture (run one eager step first)")
+                self.__dict__["_clip_plan"] = plan
+            if plan is not None and all(g.device == g0.device and g.dtype == torch.float32 for g in grads):
+                plan.run(grads, self.grad_clip_norm)
+                return
         if any(g.device != g0.device or g.dtype != g0.dtype or g.is_sparse for g in grads):
             torch.nn.utils.clip_grad_norm_([p for p in self._params if p.grad is not None], self.grad_clip_norm)
             return

@@ -1176,3 +1176,39 @@ def test_conv_halo_tile(shape, mode):
         src = stat_src.reshape(rows, 128, Cout)
         torch.testing.assert_close(s1[:, 0], src.sum(1), rtol=1e-3, atol=1e-3 * float(src.abs().sum(1).max()))
         torch.testing.assert_close(s1, s0, rtol=1e-4, atol=1e-4 * float(s0.abs().max()))
+
+
+@pytest.mark.parametrize("count,max_norm", [(7, 0.1), (337, 0.1), (40, 1e9)])
+def test_grad_clip_matches_clip_grad_norm(count, max_norm):
+    """sihl_grad_clip (Trainer._clip_gradients) against torch.nn.utils.clip_grad_norm_ (the reference's Lightning
+    gradient_clip_val, examples/object_detection.py:288-296): the same total norm and the same scaled gradients, on odd sizes,
+    channels-last tensors, 4-byte-aligned views and more than one 320-tensor group; an unreachable max_norm leaves every bit."""
+    from sihl_amd import ops
+    g = torch.Generator().manual_seed(count)
+    sizes = [int(torch.randint(1, 200_000, (1,), generator=g)) for _ in range(count)]
+    sizes[0] = 1
+    sizes[1 % count] = 3 * (1 << 16) + 5
+    grads = []
+    for k, n in enumerate(sizes):
+        if k % 5 == 2 and n >= 36:  # a conv weight's gradient: [Cout][KH][KW][Cin] memory seen as NCHW
+            c = n // 9
+            grads.append(torch.randn(c, 3, 3, 1, generator=g).cuda().permute(0, 3, 1, 2))
+        elif k % 5 == 3:            # a view that starts 4 bytes into its storage
+            grads.append(torch.randn(n + 1, generator=g).cuda()[1:])
+        else:
+            grads.append(torch.randn(n, generator=g).cuda())
+    params = [torch.nn.Parameter(torch.zeros_like(x)) for x in grads]
+    for p, x in zip(params, grads):
+        p.grad = x.clone() if x.is_contiguous() else x.clone(memory_format=torch.preserve_format)
+    want_total = torch.nn.utils.clip_grad_norm_(params, max_norm)
+    assert ops.grad_clip_supported(grads)
+    plan = ops.GradClipPlan([x.numel() for x in grads], grads[0].device)
+    before = [x.clone() for x in grads]
+    coef, total = plan.run(grads, max_norm).tolist()
+    assert total == pytest.approx(float(want_total), rel=2e-6)
+    assert coef == pytest.approx(min(1.0, max_norm / (float(want_total) + 1e-6)), rel=2e-6)
+    for x, p, b in zip(grads, params, before):
+        if max_norm > 1e6:
+            assert torch.equal(x, b)
+        else:
+            torch.testing.assert_close(x, p.grad, rtol=4e-6, atol=0)
