@@ -215,6 +215,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_wgrad_dma_kernel(const W
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef SIHL_WGRAD_STAMPS
+  unsigned long long w_entry, w_loop_end = 0, w_rt0 = 0, w_rt1 = 0;
+  WG_T(w_entry);
+#endif
   const int wm = wave >> 2, wn = wave & 3;  // (NW / 4) x 4 waves, each MI * 32 co x 64 ci
   const int ntaps = p.KH * p.KW;
   // Block -> (group, tap) with the taps of one (co panel, ci panel, K-split) group on ONE XCD and adjacent in
@@ -344,6 +348,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_wgrad_dma_kernel(const W
 #ifdef SIHL_WGRAD_STAMPS
     unsigned long long w_t0, w_t1, w_t2, w_t3, w_comp = 0, w_wait = 0, w_bar = 0, w_start;
     WG_T(w_start);
+    w_rt0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
     for (int s = 0; s < nstages; ++s) {
       const bool more = s + 1 < nstages;
@@ -369,7 +375,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_wgrad_dma_kernel(const W
     if (g_wgrad_stamps && blockIdx.x == 0 && lane == 0) {
       unsigned long long* o = g_wgrad_stamps + wave * 5;
       o[0] = w_t3 - w_start; o[1] = w_comp; o[2] = w_wait; o[3] = w_bar; o[4] = (unsigned long long)nstages;
+      g_wgrad_stamps[80 + wave * 4 + 0] = w_start - w_entry;
     }
+    w_loop_end = w_t3;
+    w_rt1 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
   }
 
@@ -386,6 +396,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_wgrad_dma_kernel(const W
           p.ws[(((long)split * p.Cout + co) * ntaps + tap) * p.Cin + ci] = acc[i][j][r];
       }
     }
+#ifdef SIHL_WGRAD_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned long long w_end;
+  WG_T(w_end);
+  if (g_wgrad_stamps && blockIdx.x == 0 && lane == 0) {
+    g_wgrad_stamps[80 + wave * 4 + 1] = w_end - w_loop_end;
+    g_wgrad_stamps[80 + wave * 4 + 2] = w_rt1 - w_rt0;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -631,6 +650,16 @@ WgradPlan plan_wgrad(long M, int N, int H, int W, int Cin, int Cout, int KH, int
   pl.kp = dtype == SIHL_BF16 ? 64 : 32;
   pl.tiles_co = (Cout + tb - 1) / tb; pl.tiles_ci = (Cin + tb - 1) / tb;
   pl.splits = choose_splits(M, KH * KW * pl.tiles_co * pl.tiles_ci, pl.kp, dma ? (g_wgrad_target > 0 ? g_wgrad_target : 256) : (g_wgrad_target_reg > 0 ? 2 * g_wgrad_target_reg : 512), n_weights);
+  if (dma && KH * KW > 1) {
+    // The LDS-DMA kernel keeps the KH*KW tap-workgroups of a (tile, split) group on ONE XCD, groups dealt round-robin over
+    // the 8 XCDs, one workgroup per CU: an XCD given more than 32 workgroups runs a second, mostly empty round (3x3,
+    // 256 -> 256 aimed at 256 workgroups: 28 groups = 36 workgroups on four of the XCDs, 253 us where one round of 24
+    // groups takes 160).  Fewer splits, so that every XCD's share fits its 32 CUs at once.
+    const int ntaps = KH * KW, tiles = pl.tiles_co * pl.tiles_ci;
+    const long per_xcd = ((long)tiles * pl.splits + 7) / 8 * ntaps;
+    const long one_round = 8L * (32 / ntaps) / tiles;  // splits that fill one round
+    if (per_xcd > 32 && per_xcd <= 48 && one_round >= 1) pl.splits = (int)one_round;
+  }
   return pl;
 }
 
