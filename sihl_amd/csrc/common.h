@@ -114,3 +114,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     hipError_t e__ = hipGetLastError();         \
     if (e__ != hipSuccess) return (int)e__;     \
   } while (0)
+
+// Progress-based issue priority inside a K-loop stage (s_setprio, 0-3): a wave lowers its priority as it advances from one stage
+// barrier to the next.  The SIMD's arbiter serves its OLDEST ready wave first, so without this the waves of a SIMD finish a
+// stage one after the other: the oldest idles at the barrier (43 % of the weight-gradient loop), the youngest runs the end
+// of every stage alone with its LDS latencies exposed (tools/wgrad_stamps.py).  Measured (profiles/r04_prio_lib_ab.txt,
+// r04_wgrad_stamps.txt): weight-gradient loop 3 086 -> 2 890 cycles per stage; the forward tiles (conv_igemm 256 x 256,
+// conv_halo) unchanged.  The priority is SIMD-wide, across kernels: a weight gradient running BESIDE the dgrad chain on a
+// second stream took issue slots from the critical path's kernels (step 26.83 -> 27.16 ms), so the kernel raises it only
+// when it has the device to itself (WgradParams::prio).
+#define SIHL_PRIO(n) __builtin_amdgcn_s_setprio(n)

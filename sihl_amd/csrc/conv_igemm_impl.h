@@ -686,6 +686,8 @@ __global__ __launch_bounds__(WM * WN * 64, (conv_min_waves<BM, BN, WM * WN>())) 
       }
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
+        // (tried: issue priority falling as the wave advances through the stage, common.h SIHL_PRIO - it evens out the waves of
+        // the weight-gradient loop, here and in conv_halo.hip it changed nothing: profiles/r04_prio_lib_ab.txt)
         if (ks + 1 < NKS) {  // fragments of the next k-step are in flight while this one multiplies
 #pragma unroll
           for (int i = 0; i < MT; ++i) fa[(ks + 1) & 1][i] = *(const uint4*)(As + i * TILE * KCB + koff[ks + 1]);

@@ -55,6 +55,12 @@ for k, d in agg.items():
     if 'SQ_VALU_MFMA_BUSY_CYCLES' in m and 'SQ_BUSY_CU_CYCLES' in m:
         print(f"   matrix pipe busy / CU busy: {m['SQ_VALU_MFMA_BUSY_CYCLES'] / 4 / m['SQ_BUSY_CU_CYCLES']:.3f} (MFMA busy cycles summed over the 4 SIMDs of a CU / 4)")
 PY
+# weight gradients: slab bytes of a step, K-loop stamps of the panel kernel (diagnostic build, if present), host phases
+timeout -k 10 200 python tools/wgrad_slab_probe.py > $OUT/wgrad_slab_probe.txt 2>&1
+if [ -f tools/micro/tuning_build/libsihl_hip_wstamps.so ]; then
+  SIHL_HIP_LIB=$PWD/tools/micro/tuning_build/libsihl_hip_wstamps.so timeout -k 10 120 python tools/wgrad_stamps.py > $OUT/wgrad_stamps.txt 2>&1
+fi
+timeout -k 10 200 python tools/host_phases.py > $OUT/host_phases.txt 2>&1
 # secondary configurations on the final tree
 timeout -k 10 600 python tools/config_probe.py > $OUT/config_probe.txt 2>&1
 # the bench line WITH this tree's measured traffic (profiles/r04_pmc_bench.json carries the same source stamp), CPU baseline at bs 32
