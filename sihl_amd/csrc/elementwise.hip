@@ -9,6 +9,17 @@
 //   * LayerNorm + SiLU of the MLP hidden layers and its backward             (heads/object_detection.py:51-61)
 #include "common.h"
 
+// Every kernel of this file runs on the training step's MAIN stream; the weight gradients run beside them on a second stream
+// (1 024-thread workgroups that hold a CU's LDS but not all of its wave slots).  s_setprio is SIMD-wide, across kernels: at
+// priority 3 these memory-bound kernels take the issue slot as soon as their data is back instead of queueing behind the
+// neighbour's MFMA stream - step 27.10 -> 26.75 ms (profiles/r04_ewprio_lib_ab.txt, alternating processes; -DSIHL_EW_NO_PRIO is
+// the A/B build).  The same on the conv kernels changed nothing (r04_mainprio_lib_ab.txt) and is not there.
+#ifdef SIHL_EW_NO_PRIO
+#define EW_PRIO() do { } while (0)
+#else
+#define EW_PRIO() SIHL_PRIO(3)
+#endif
+
 namespace {
 
 constexpr int TPB = 256;
@@ -68,6 +79,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int R, int C,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* running_mean, float* running_var, float* mean_out,
                                    float* rstd_out, float* scale, float* shift) {
+  EW_PRIO();
   // One workgroup per 4 channels (layers with few channels still spread over C/4 workgroups).  When C % 4 == 0 every
   // thread owns whole partial rows and reads the 4 sums and 4 squared sums of a row as two 16-byte loads (the
   // stage-1 layers have 4096 partial rows: 64 scalar loads per thread took ~15 us); the 256 threads are then folded
@@ -131,6 +143,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int R, int C,
 // scale/shift from running statistics (eval mode)
 __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
                                       float eps, int C, float* scale, float* shift) {
+  EW_PRIO();
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const float rstd = 1.f / sqrtf(rv[c] + eps);
@@ -165,6 +178,7 @@ template <typename T, int ACT, bool FIXED>
 __global__ void affine_act_kernel(const T* __restrict__ x, T* __restrict__ y, long nvec, int cvec,
                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                   const T* __restrict__ res, unsigned char* __restrict__ mask) {
+  EW_PRIO();
   constexpr int V = 16 / sizeof(T);
   float sc[V], sh[V];
   const long i0 = (long)blockIdx.x * TPB + threadIdx.x;
@@ -206,6 +220,7 @@ __global__ void affine_act_kernel(const T* __restrict__ x, T* __restrict__ y, lo
 template <typename T, int ACT, bool FIXED>
 __global__ void affine_act_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, long nvec,
                                       int cvec, const float* __restrict__ scale, const float* __restrict__ shift) {
+  EW_PRIO();
   constexpr int V = 16 / sizeof(T);
   float sc[V], sh[V];
   const long i0 = (long)blockIdx.x * TPB + threadIdx.x;
@@ -233,6 +248,7 @@ __global__ void affine_act_bwd_kernel(const T* __restrict__ x, const T* __restri
 // ------------------------------------------------------------------ out = act(a + b)  (ResNet residual merge)
 template <typename T, int ACT>
 __global__ void add_act_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, long nvec) {
+  EW_PRIO();
   constexpr int V = 16 / sizeof(T);
   for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long)gridDim.x * TPB) {
     float fa[V], fb[V];
@@ -266,6 +282,7 @@ __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >
 template <typename T>
 __global__ void fuse_up2_kernel(const T* __restrict__ a, const T* __restrict__ b, const float* __restrict__ wraw,
                                 T* __restrict__ out, int N, int H, int W, int C) {
+  EW_PRIO();
   constexpr int V = 16 / sizeof(T);
   const unsigned cvec = C / V, h2 = H / 2, w2 = W / 2;
   const unsigned xc = blockIdx.x * TPB + threadIdx.x;
@@ -300,6 +317,7 @@ template <typename T>
 __global__ void fuse_up2_bwd_hi_kernel(const T* __restrict__ dout, const T* __restrict__ a, const T* __restrict__ b,
                                        const float* __restrict__ wraw, T* __restrict__ db, float* gacc, int N, int H,
                                        int W, int C) {
+  EW_PRIO();
   constexpr int V = 16 / sizeof(T);
   const int cvec = C / V, h2 = H / 2, w2 = W / 2;
   const long nvec = (long)N * H * W * cvec;
@@ -343,6 +361,7 @@ __global__ void fuse_up2_bwd_hi_kernel(const T* __restrict__ dout, const T* __re
 template <typename T>
 __global__ void up2_adjoint_kernel(const T* __restrict__ dout, const float* __restrict__ wraw, T* __restrict__ da,
                                    int N, int H, int W, int C) {
+  EW_PRIO();
   constexpr int V = 16 / sizeof(T);
   const int cvec = C / V, h2 = H / 2, w2 = W / 2;
   const long nvec = (long)N * h2 * w2 * cvec;
@@ -392,6 +411,7 @@ __global__ void up2_adjoint_kernel(const T* __restrict__ dout, const float* __re
 template <typename T>
 __global__ void nearest_up2_add_kernel(const T* __restrict__ lo, const T* __restrict__ skip, T* __restrict__ out,
                                        int N, int H, int W, int C) {
+  EW_PRIO();
   constexpr int V = 16 / sizeof(T);
   const int cvec = C / V, h2 = H / 2, w2 = W / 2;
   const long nvec = (long)N * H * W * cvec;
@@ -414,6 +434,7 @@ __global__ void nearest_up2_add_kernel(const T* __restrict__ lo, const T* __rest
 template <typename T>
 __global__ void nearest_up2_adjoint_kernel(const T* __restrict__ dout, T* __restrict__ dlo, int N, int H, int W,
                                            int C) {
+  EW_PRIO();
   constexpr int V = 16 / sizeof(T);
   const int cvec = C / V, h2 = H / 2, w2 = W / 2;
   const long nvec = (long)N * h2 * w2 * cvec;
@@ -454,6 +475,7 @@ __device__ __forceinline__ Lerp resize_src(int dst, int in_size, float scale) {
 template <typename T>
 __global__ void resize_bilinear_kernel(const T* __restrict__ a, const T* __restrict__ add, T* __restrict__ out, int N,
                                        int H, int W, int Ho, int Wo, int C) {
+  EW_PRIO();
   constexpr int V = 16 / sizeof(T);
   const int cvec = C / V;
   const long nvec = (long)N * Ho * Wo * cvec;
@@ -485,6 +507,7 @@ __global__ void resize_bilinear_kernel(const T* __restrict__ a, const T* __restr
 template <typename T>
 __global__ void resize_bilinear_adjoint_kernel(const T* __restrict__ dout, T* __restrict__ da, int N, int H, int W,
                                                int Ho, int Wo, int C) {
+  EW_PRIO();
   constexpr int V = 16 / sizeof(T);
   const int cvec = C / V;
   const long nvec = (long)N * H * W * cvec;
@@ -531,6 +554,7 @@ __global__ void blur_fuse_kernel(const T* __restrict__ a, const T* __restrict__ 
                                  const float* __restrict__ wraw, const float* __restrict__ a_scale,
                                  const float* __restrict__ a_shift, T* __restrict__ out, int N, int H, int W, int Ho,
                                  int Wo, int C) {
+  EW_PRIO();
   constexpr int V = 16 / sizeof(T);
   const unsigned cvec = C / V;
   const unsigned xc = blockIdx.x * TPB + threadIdx.x;
@@ -586,6 +610,7 @@ __global__ void blur_fuse_bwd_lo_kernel(const T* __restrict__ dout, const T* __r
                                         const float* __restrict__ a_scale, const float* __restrict__ a_shift,
                                         T* __restrict__ db, T* __restrict__ dc, float* gacc, int N, int H, int W, int Ho,
                                         int Wo, int C) {
+  EW_PRIO();
   constexpr int V = 16 / sizeof(T);
   const int cvec = C / V;
   const long nvec = (long)N * Ho * Wo * cvec;
@@ -649,6 +674,7 @@ __global__ void blur_fuse_bwd_lo_kernel(const T* __restrict__ dout, const T* __r
 template <typename T>
 __global__ void blur_adjoint_kernel(const T* __restrict__ dout, const float* __restrict__ wraw, T* __restrict__ da,
                                     int N, int H, int W, int Ho, int Wo, int C) {
+  EW_PRIO();
   constexpr int V = 16 / sizeof(T);
   const int cvec = C / V;
   const long nvec = (long)N * H * W * cvec;
@@ -701,6 +727,7 @@ __global__ void blur_adjoint_kernel(const T* __restrict__ dout, const float* __r
 template <typename T>
 __global__ void fuse_sum_kernel(const T* __restrict__ x0, const T* __restrict__ x1, const T* __restrict__ x2,
                                 const float* __restrict__ wraw, T* __restrict__ out, long nvec, int n) {
+  EW_PRIO();
   constexpr int V = 16 / sizeof(T);
   float w[3];
   softmax_w(wraw, n, w);
@@ -719,6 +746,7 @@ template <typename T>
 __global__ void fuse_sum_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ x0, const T* __restrict__ x1,
                                     const T* __restrict__ x2, const float* __restrict__ wraw, T* __restrict__ d0,
                                     T* __restrict__ d1, T* __restrict__ d2, float* gacc, long nvec, int n) {
+  EW_PRIO();
   constexpr int V = 16 / sizeof(T);
   float w[3];
   softmax_w(wraw, n, w);
@@ -755,6 +783,7 @@ __global__ void fuse_sum_bwd_kernel(const T* __restrict__ dout, const T* __restr
 // g = sum of the producing kernel's per-workgroup partial rows part[nblocks][4] (fixed order: strided per thread, then a
 // tree through LDS); d raw_j = w_j * (g_j - sum_i w_i g_i)  (softmax Jacobian) -> dw_raw
 __global__ void fusion_wgrad_kernel(const float* wraw, const float* __restrict__ part, int nblocks, float* dw_raw, int n) {
+  EW_PRIO();
   __shared__ float red[3][256];
   float a[3] = {0.f, 0.f, 0.f};
   for (int b = threadIdx.x; b < nblocks; b += 256)
@@ -791,6 +820,7 @@ __global__ void norm_bwd_reduce_kernel(const T* __restrict__ s, const T* __restr
                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                        float* __restrict__ part, int rows_per_block, int nrl, int rev,
                                        const void* __restrict__ ymask = nullptr, T* __restrict__ dres = nullptr) {
+  EW_PRIO();
   constexpr int V = 16 / sizeof(T);
   const int cvec = C / V;
   // rows of a workgroup: a contiguous range (rev 0), or - rev - row lanes dealt round by round over the whole grid and
@@ -862,6 +892,7 @@ __global__ void norm_bwd_reduce_kernel(const T* __restrict__ s, const T* __restr
 // spread over 32+ CUs).
 __global__ void colsum_finalize_kernel(const float* __restrict__ part, int R, int K, int C, float* __restrict__ out0,
                                        float* __restrict__ out1) {
+  EW_PRIO();
   __shared__ double sh[64][5];
   const int cx = threadIdx.x & 3, ry = threadIdx.x >> 2;
   const int idx = blockIdx.x * 4 + cx, KC = K * C;
@@ -891,6 +922,7 @@ __global__ void norm_bwd_apply_kernel(const T* __restrict__ s, const T* __restri
                                       const float* __restrict__ sum_g /*dbeta*/, const float* __restrict__ sum_gx /*dgamma*/,
                                       float inv_count,
                                       int batch_stats) {
+  EW_PRIO();
   constexpr int V = 16 / sizeof(T);
   const int C = cvec * V;
   float mu[V], rs[V], ga[V], be[V], k0[V], k1[V];
@@ -939,6 +971,7 @@ __global__ void __launch_bounds__(TPB)
 layernorm_act_kernel(const T* __restrict__ z, T* __restrict__ y, long rows, int C, const float* __restrict__ gamma,
                      const float* __restrict__ beta, float eps, float* __restrict__ mean_out,
                      float* __restrict__ rstd_out) {
+  EW_PRIO();
   constexpr int V = 16 / sizeof(T), RPW = 64 / SUB;
   const int cvec = C / V, lane = threadIdx.x & 63, sub = lane % SUB, rsel = lane / SUB;
   const long wave = ((long)blockIdx.x * TPB + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * TPB) >> 6;
@@ -995,6 +1028,7 @@ __global__ void __launch_bounds__(TPB)
 layernorm_act_bwd_kernel(const T* __restrict__ z, const T* __restrict__ dy, T* __restrict__ dz, long rows, int C,
                          const float* __restrict__ gamma, const float* __restrict__ beta,
                          const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ part) {
+  EW_PRIO();
   constexpr int V = 16 / sizeof(T), RPW = 64 / SUB;
   const int cvec = C / V, lane = threadIdx.x & 63, sub = lane % SUB, rsel = lane / SUB;
   const long wave = ((long)blockIdx.x * TPB + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * TPB) >> 6;
@@ -1091,6 +1125,7 @@ layernorm_act_bwd_kernel(const T* __restrict__ z, const T* __restrict__ dy, T* _
 template <typename T, bool VECTOR>
 __global__ void colsum_partial_kernel(const T* __restrict__ x, long rows, int C, float* __restrict__ part,
                                       int rows_per_block, int nrl) {
+  EW_PRIO();
   constexpr int V = 16 / sizeof(T);
   __shared__ float red[TPB * V];  // nrl * C <= TPB * V floats whenever nrl > 1
   const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
@@ -1142,6 +1177,7 @@ __global__ void colsum_partial_kernel(const T* __restrict__ x, long rows, int C,
 template <typename TI, typename TO>
 __global__ void weight_flip_transpose_kernel(const TI* __restrict__ w, TO* __restrict__ o, int Cout, int KH, int KW,
                                              int Cin, int flip) {
+  EW_PRIO();
   const long n = (long)Cout * KH * KW * Cin;
   for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) {
     long t = i;
@@ -1195,6 +1231,7 @@ __device__ __forceinline__ const WeightDesc* find_desc(const WeightDesc* descs, 
 
 // w [Op][KH][KW][I]: same element order as a channels-last master weight, so reads and writes are both contiguous
 __global__ void weight_prepare_kernel(const WeightDesc* __restrict__ descs, int n) {
+  EW_PRIO();
   const WeightDesc d = *find_desc(descs, n, blockIdx.x, false);
   const long total = (long)d.Op * d.KH * d.KW * d.I;
   const long e0 = ((long)blockIdx.x - d.first_block) * 2048 + threadIdx.x * 8;
@@ -1227,6 +1264,7 @@ __global__ void weight_prepare_kernel(const WeightDesc* __restrict__ descs, int 
 // weight is read along i (its contiguous axis when channels-last) and the copy is written along o.  (Gathering the
 // source per destination element fetched 11x the bytes: 2.2 GB for 193 MB of weights.)
 __global__ void weight_prepare_t_kernel(const WeightDesc* __restrict__ descs, int n) {
+  EW_PRIO();
   __shared__ float tile[64][65];
   const WeightDesc d = *find_desc(descs, n, blockIdx.x, true);
   long b = (long)blockIdx.x - d.first_tblock;
@@ -1257,6 +1295,7 @@ __global__ void weight_prepare_t_kernel(const WeightDesc* __restrict__ descs, in
 template <typename T>
 __global__ void maxpool3x3s2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, unsigned char* __restrict__ idx,
                                         long nvec, int H, int W, int Ho, int Wo, int cv) {
+  EW_PRIO();
   constexpr int V = 16 / (int)sizeof(T);
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % cv);
@@ -1305,6 +1344,7 @@ __global__ void maxpool3x3s2_fwd_kernel(const T* __restrict__ x, T* __restrict__
 template <typename T>
 __global__ void maxpool3x3s2_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx, T* __restrict__ dx,
                                         long nvec, int H, int W, int Ho, int Wo, int cv) {
+  EW_PRIO();
   constexpr int V = 16 / (int)sizeof(T);
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % cv);
@@ -1632,6 +1672,7 @@ namespace {
 constexpr int CLIP_MAXT = 320, CLIP_CHUNK = 1 << 16;
 struct ClipPtrs { float* p[CLIP_MAXT]; };
 __global__ void clip_sumsq_kernel(const ClipPtrs ptrs, const int* __restrict__ map, const long* __restrict__ numel, float* __restrict__ part) {
+  EW_PRIO();
   const int t = map[2 * blockIdx.x], c = map[2 * blockIdx.x + 1];
   const float* __restrict__ x = ptrs.p[t] + (long)c * CLIP_CHUNK;
   const long left = numel[t] - (long)c * CLIP_CHUNK;
@@ -1659,6 +1700,7 @@ __global__ void clip_sumsq_kernel(const ClipPtrs ptrs, const int* __restrict__ m
   }
 }
 __global__ void clip_finish_kernel(const float* __restrict__ part, int nblocks, float max_norm, float* __restrict__ out) {
+  EW_PRIO();
   __shared__ double red[256];
   double a = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += 256) a += (double)part[b];
@@ -1676,6 +1718,7 @@ __global__ void clip_finish_kernel(const float* __restrict__ part, int nblocks, 
   }
 }
 __global__ void clip_scale_kernel(const ClipPtrs ptrs, const int* __restrict__ map, const long* __restrict__ numel, const float* __restrict__ out) {
+  EW_PRIO();
   const float coef = out[0];
   if (coef >= 1.f) return;  // (NaN fails the test and scales, like the reference)
   const int t = map[2 * blockIdx.x], c = map[2 * blockIdx.x + 1];
