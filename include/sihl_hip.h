@@ -217,12 +217,13 @@ int sihl_blur_fuse_bwd(const void* dout, const void* a, const void* b, const voi
 /* Gradient-norm clipping of n dense fp32 tensors (torch.nn.utils.clip_grad_norm_, the reference's Lightning
  * gradient_clip_val, examples/object_detection.py:288-296): total = sqrt(sum of squares of everything), every tensor *= min(1,
  * max_norm / (total + 1e-6)).  Three launches per 320 tensors instead of the library's per-tensor result tensors.
- * grads: HOST array of n device pointers, taken in groups of 320; group_blocks: HOST int [ceil(n / 320)], workgroups per group;
+ * grads: HOST array of n device pointers, taken in groups of `group` (32 or 320: the pointer table rides by value in the launch
+ * arguments); group_blocks: HOST int [ceil(n / group)], workgroups per group;
  * map: DEVICE int32 [sum(group_blocks)][2] = (tensor index within its group, 65 536-element chunk) per workgroup and numel:
  * DEVICE int64 [n] - functions of the sizes only, built once by the caller; scratch: sum(group_blocks) + 2 floats; on return
  * (stream order) scratch[nblocks] = the coefficient, scratch[nblocks + 1] = the total norm. */
 int sihl_grad_clip(const void* const* grads, int n, const int* map, const int* group_blocks, const long* numel, float max_norm,
-                   float* scratch, long scratch_floats, hipStream_t stream);
+                   float* scratch, long scratch_floats, int group, hipStream_t stream);
 
 /* 3x3 / stride 1 / pad 1 conv of the pyramid's TOP levels with its fusion node folded into the loader (bf16; square maps of
  * W = 16, 8 or 4; csrc/conv_pyr.hip).  One launch replaces [fusion kernel -> conv -> split-K finish] of a BiFPNLayer node

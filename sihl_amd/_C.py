@@ -85,7 +85,7 @@ SIGNATURES = {
     "sihl_pyr_conv_supported": (I, [I, I, I, I, I]),
     "sihl_pyr_conv_stat_rows": (I, [I, I]),
     "sihl_pyr_conv_fwd": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, I, P, L, I, P, P, P, P, P, P, P, I, P, P, P, P, P]),
-    "sihl_grad_clip": (I, [P, I, P, P, P, F, P, L, P]),
+    "sihl_grad_clip": (I, [P, I, P, P, P, F, P, L, I, P]),
     "sihl_blur_fuse_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "sihl_layernorm_act": (I, [P, P, L, I, P, P, F, I, P, P, I, P]),
     "sihl_layernorm_bwd_waves": (I, [L]),

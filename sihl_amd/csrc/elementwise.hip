@@ -1669,9 +1669,10 @@ int sihl_fuse_sum_bwd(const void* dout, const void* x0, const void* x1, const vo
 // multi-tensor library routines and, above all, without their 320 result tensors (2.8 ms of host time per step).
 }  // extern "C" (reopened below)
 namespace {
-constexpr int CLIP_MAXT = 320, CLIP_CHUNK = 1 << 16;
-struct ClipPtrs { float* p[CLIP_MAXT]; };
-__global__ void clip_sumsq_kernel(const ClipPtrs ptrs, const int* __restrict__ map, const long* __restrict__ numel, float* __restrict__ part) {
+constexpr int CLIP_CHUNK = 1 << 16;
+template <int MAXT> struct ClipPtrs { float* p[MAXT]; };
+template <int MAXT>
+__global__ void clip_sumsq_kernel(const ClipPtrs<MAXT> ptrs, const int* __restrict__ map, const long* __restrict__ numel, float* __restrict__ part) {
   EW_PRIO();
   const int t = map[2 * blockIdx.x], c = map[2 * blockIdx.x + 1];
   const float* __restrict__ x = ptrs.p[t] + (long)c * CLIP_CHUNK;
@@ -1717,7 +1718,8 @@ __global__ void clip_finish_kernel(const float* __restrict__ part, int nblocks, 
     out[1] = total;
   }
 }
-__global__ void clip_scale_kernel(const ClipPtrs ptrs, const int* __restrict__ map, const long* __restrict__ numel, const float* __restrict__ out) {
+template <int MAXT>
+__global__ void clip_scale_kernel(const ClipPtrs<MAXT> ptrs, const int* __restrict__ map, const long* __restrict__ numel, const float* __restrict__ out) {
   EW_PRIO();
   const float coef = out[0];
   if (coef >= 1.f) return;  // (NaN fails the test and scales, like the reference)
@@ -1737,43 +1739,51 @@ __global__ void clip_scale_kernel(const ClipPtrs ptrs, const int* __restrict__ m
     for (int i = threadIdx.x; i < len; i += TPB) x[i] *= coef;
   }
 }
-}  // namespace
-extern "C" {
 
-// grads: HOST array of n device pointers to dense fp32 tensors, taken in groups of 320 (one launch's argument block);
-// group_blocks: HOST int [ceil(n / 320)], the workgroups of each group; map: DEVICE int32 [sum of group_blocks][2] = (tensor
-// index WITHIN its group, 64 Ki-element chunk) of every workgroup, group after group; numel: DEVICE int64 [n] - map and numel
-// depend on the sizes only (the caller builds them once per model); scratch: DEVICE floats, nblocks + 2: the partial sums,
-// then (coefficient, total norm).
-int sihl_grad_clip(const void* const* grads, int n, const int* map, const int* group_blocks, const long* numel, float max_norm,
-                   float* scratch, long scratch_floats, hipStream_t stream) {
-  if (!grads || n <= 0 || !map || !group_blocks || !numel || !scratch || !(max_norm > 0.f)) return SIHL_EARG;
-  const int groups = (n + CLIP_MAXT - 1) / CLIP_MAXT;
+template <int MAXT>
+int grad_clip_launch(const void* const* grads, int n, const int* map, const int* group_blocks, const long* numel, float max_norm,
+                     float* scratch, long scratch_floats, hipStream_t stream) {
+  const int groups = (n + MAXT - 1) / MAXT;
   long nblocks = 0;
   for (int g = 0; g < groups; ++g) {
     if (group_blocks[g] <= 0) return SIHL_EARG;
     nblocks += group_blocks[g];
   }
   if (scratch_floats < nblocks + 2 || nblocks > (1 << 24)) return SIHL_EARG;
-  for (int k = 0; k < n; ++k)
-    if (!grads[k] || (((unsigned long)grads[k]) & 3)) return SIHL_EARG;
   auto group_ptrs = [&](int g) {
-    ClipPtrs ptrs;
-    const int first = g * CLIP_MAXT, m = n - first < CLIP_MAXT ? n - first : CLIP_MAXT;
-    for (int k = 0; k < CLIP_MAXT; ++k) ptrs.p[k] = (float*)grads[first + (k < m ? k : 0)];
+    ClipPtrs<MAXT> ptrs;
+    const int first = g * MAXT, m = n - first < MAXT ? n - first : MAXT;
+    for (int k = 0; k < MAXT; ++k) ptrs.p[k] = (float*)grads[first + (k < m ? k : 0)];
     return ptrs;
   };
   long b0 = 0;
   for (int g = 0; g < groups; b0 += group_blocks[g], ++g)
-    hipLaunchKernelGGL(clip_sumsq_kernel, dim3(group_blocks[g]), dim3(TPB), 0, stream, group_ptrs(g), map + 2 * b0,
-                       numel + (long)g * CLIP_MAXT, scratch + b0);
+    hipLaunchKernelGGL(clip_sumsq_kernel<MAXT>, dim3(group_blocks[g]), dim3(TPB), 0, stream, group_ptrs(g), map + 2 * b0,
+                       numel + (long)g * MAXT, scratch + b0);
   hipLaunchKernelGGL(clip_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)scratch, (int)nblocks, max_norm, scratch + nblocks);
   b0 = 0;
   for (int g = 0; g < groups; b0 += group_blocks[g], ++g)
-    hipLaunchKernelGGL(clip_scale_kernel, dim3(group_blocks[g]), dim3(TPB), 0, stream, group_ptrs(g), map + 2 * b0,
-                       numel + (long)g * CLIP_MAXT, (const float*)(scratch + nblocks));
+    hipLaunchKernelGGL(clip_scale_kernel<MAXT>, dim3(group_blocks[g]), dim3(TPB), 0, stream, group_ptrs(g), map + 2 * b0,
+                       numel + (long)g * MAXT, (const float*)(scratch + nblocks));
   SIHL_CHECK_LAUNCH();
   return SIHL_OK;
+}
+}  // namespace
+extern "C" {
+
+// grads: HOST array of n device pointers to dense fp32 tensors, taken in groups of `group` (32 or 320: one launch's by-value
+// pointer table); group_blocks: HOST int [ceil(n / group)], the workgroups of each group; map: DEVICE int32
+// [sum of group_blocks][2] = (tensor index WITHIN its group, 64 Ki-element chunk) of every workgroup, group after group;
+// numel: DEVICE int64 [n] - map and numel depend on the sizes only (the caller builds them once per model); scratch: DEVICE
+// floats, nblocks + 2: the partial sums, then (coefficient, total norm).
+int sihl_grad_clip(const void* const* grads, int n, const int* map, const int* group_blocks, const long* numel, float max_norm,
+                   float* scratch, long scratch_floats, int group, hipStream_t stream) {
+  if (!grads || n <= 0 || !map || !group_blocks || !numel || !scratch || !(max_norm > 0.f)) return SIHL_EARG;
+  for (int k = 0; k < n; ++k)
+    if (!grads[k] || (((unsigned long)grads[k]) & 3)) return SIHL_EARG;
+  if (group == 320) return grad_clip_launch<320>(grads, n, map, group_blocks, numel, max_norm, scratch, scratch_floats, stream);
+  if (group == 32) return grad_clip_launch<32>(grads, n, map, group_blocks, numel, max_norm, scratch, scratch_floats, stream);
+  return SIHL_EARG;
 }
 
 // out[N][Ho][Wo][C] = w0*blurpool_s2(a[N][H][W][C]) + w1*b + w2*c ; b==c==null -> plain blur pool

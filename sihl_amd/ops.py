@@ -135,6 +135,9 @@ WGRAD_SIDE_MAX_PIXELS = {"off": 0, "small": 32 * 32 * 32, "all": 1 << 62}
 # CU write half the fp32 partial slabs and leave CUs to the main stream (flagship step, same box: 35.4-35.8 ->
 # 34.4-34.7 ms; 64-96 workgroups about the same, 32: 40.2 ms)
 SIDE_WGRAD_TARGET = 128 + 10000 * 128
+if os.environ.get("SIHL_SIDE_WGRAD_TARGET"):  # developer A/B: "<LDS-DMA aim>[,<register-staged aim>]"
+    _t = [int(v) for v in os.environ["SIHL_SIDE_WGRAD_TARGET"].split(",")]
+    SIDE_WGRAD_TARGET = _t[0] + 10000 * (_t[1] if len(_t) > 1 else 128)
 WGRAD_TARGET = 0  # K-split aim of weight gradients on the main stream (0 = library default, one workgroup per CU)
 
 
@@ -1137,7 +1140,7 @@ class GradClipPlan:
     """Static tables of sihl_grad_clip for one list of gradient sizes: (tensor, 64 Ki-element chunk) per workgroup, the
     element counts, the scratch row.  Built once per model; ``run`` is three launches and no tensor creation."""
 
-    GROUP, CHUNK = 320, 1 << 16
+    GROUP, CHUNK = int(os.environ.get("SIHL_CLIP_GROUP", "320")), 1 << 16  # (developer A/B: 32)
 
     def __init__(self, numels, device):
         import ctypes
@@ -1162,7 +1165,7 @@ class GradClipPlan:
         for k, g in enumerate(grads):
             ptrs[k] = g.data_ptr()
         rc = _C.lib().sihl_grad_clip(ptrs, len(grads), _p(self.map), self.group_blocks, _p(self.numel), float(max_norm),
-                                     _p(self.scratch), self.scratch.numel(), _stream())
+                                     _p(self.scratch), self.scratch.numel(), self.GROUP, _stream())
         check(rc, "sihl_grad_clip")
         return self.scratch[self.nblocks:]
 

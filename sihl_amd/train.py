@@ -363,15 +363,18 @@ class Trainer:
         if not grads:
             return
         g0 = grads[0]
-        if g0.is_cuda:
+        # A graph Trainer keeps the multi-tensor routines, in its eager warm-up steps as well as in the capture: host time does
+        # not exist in a replay, and round 4 measured a GPU memory fault on the SECOND replay of the north-star step whenever
+        # sihl_grad_clip had run in that process before - in the capture or only in the eager warm-up steps, with 2.6 KB or
+        # 280 B of by-value pointer table - while the same launches captured alone replay correctly (tools/graph_bisect.py,
+        # tools/clip_graph_probe.py, profiles/r04_graph_clip_fault.txt).  Cause not found; eager training is unaffected.
+        if g0.is_cuda and (not self.use_graph or getattr(self, "use_graph_clip", False)):  # (use_graph_clip: tools/graph_bisect.py)
             from sihl_amd import ops
 
             plan = self.__dict__.get("_clip_plan")
             sizes = tuple(g.numel() for g in grads)
             if plan is None or plan.numels != sizes or plan.map.device != g0.device:
                 plan = ops.GradClipPlan(sizes, g0.device) if ops.grad_clip_supported(grads) else None
-                if torch.cuda.is_current_stream_capturing() and plan is not None:
-                    raise RuntimeError("gradient-clip tables must exist before graph capture (run one eager step first)")
                 self.__dict__["_clip_plan"] = plan
             if plan is not None and all(g.device == g0.device and g.dtype == torch.float32 for g in grads):
                 plan.run(grads, self.grad_clip_norm)

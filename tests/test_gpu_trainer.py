@@ -353,3 +353,4 @@ def test_sibling_heads_report_their_validation_metrics():
     out = kpt.on_validation_end()
     assert set(out) == {"PCK", "loss"} and 0.0 <= out["PCK"] <= 1.0
     assert kpt.pck_computer.total == 2 * 10  # every visible ground-truth keypoint is counted once per step, matched or not
+

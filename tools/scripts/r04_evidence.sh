@@ -65,5 +65,7 @@ timeout -k 10 200 python tools/host_phases.py > $OUT/host_phases.txt 2>&1
 timeout -k 10 600 python tools/config_probe.py > $OUT/config_probe.txt 2>&1
 # the bench line WITH this tree's measured traffic (profiles/r04_pmc_bench.json carries the same source stamp), CPU baseline at bs 32
 python bench.py --cpu-sample 32 > $OUT/bench.json 2> $OUT/bench.err
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > $OUT/gpu_tests.log 2>&1
+tail -3 $OUT/gpu_tests.log
 head -4 $OUT/off_bench_steady_state_summary.txt
 head -c 700 $OUT/bench.json
