@@ -22,6 +22,13 @@ import os
 import sys
 import time
 
+# HIP-graph replays through ROCm's "packet capture" path are not safe beside other device allocations (sihl_amd/__init__.py): the
+# switch is set here, before anything can have initialised the HIP runtime
+if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") is None:  # before the HIP runtime reads its flags: sihl_amd/__init__.py
+    os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
+    _t = sys.modules.get("torch")
+    os.environ["SIHL_GRAPH_ENV_EARLY"] = "0" if (_t is not None and _t.cuda.is_initialized()) else "1"
+
 import torch
 import torch.distributed as dist
 

@@ -220,6 +220,16 @@ class Trainer:
         on_gpu = all(p.is_cuda for p in model.parameters())
         self.use_graph = bool(graph) and world == 1 and on_gpu
         if self.use_graph:
+            import sihl_amd
+
+            if not sihl_amd.graph_replay_safe() and not os.environ.get("SIHL_ALLOW_GRAPH_PACKET_CAPTURE"):
+                raise RuntimeError(
+                    "Trainer(graph=True): HIP-graph replays of this process would go through ROCm's graph packet capture "
+                    "(DEBUG_CLR_GRAPH_PACKET_CAPTURE is not 0, or the HIP runtime was already initialised when sihl_amd was "
+                    "imported, so its default came too late).  On that path device memory the process allocates beside the "
+                    "graph can overwrite the replay's kernel arguments: silently wrong results or a GPU memory fault.  Set "
+                    "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment (or import sihl_amd before the first device call); "
+                    "SIHL_ALLOW_GRAPH_PACKET_CAPTURE=1 overrides this check.")
             # a graph Trainer is single-stream THROUGHOUT, warm-up steps included (a capture that
             # followed two-stream eager steps faulted on a later replay; the captured step never uses a second stream)
             self.wgrad_stream = opt_kw.pop("_graph_warmup_stream", "off")  # private: tools/graph_phase_probe.py only
@@ -363,12 +373,7 @@ class Trainer:
         if not grads:
             return
         g0 = grads[0]
-        # A graph Trainer keeps the multi-tensor routines, in its eager warm-up steps as well as in the capture: host time does
-        # not exist in a replay, and round 4 measured a GPU memory fault on the SECOND replay of the north-star step whenever
-        # sihl_grad_clip had run in that process before - in the capture or only in the eager warm-up steps, with 2.6 KB or
-        # 280 B of by-value pointer table - while the same launches captured alone replay correctly (tools/graph_bisect.py,
-        # tools/clip_graph_probe.py, profiles/r04_graph_clip_fault.txt).  Cause not found; eager training is unaffected.
-        if g0.is_cuda and (not self.use_graph or getattr(self, "use_graph_clip", False)):  # (use_graph_clip: tools/graph_bisect.py)
+        if g0.is_cuda:
             from sihl_amd import ops
 
             plan = self.__dict__.get("_clip_plan")
@@ -448,13 +453,12 @@ class Trainer:
         torch._foreach_copy_(static_leaves, leaves)
         graph.replay()  # ... the replay does
         if images.is_cuda:
+            import sihl_amd
             from sihl_amd import ops
-            if ops.side_stream_history():
-                # Replays queued back to back faulted (GPU memory access fault on the 2nd+ replay) in processes whose
-                # EARLIER eager steps had used the wgrad side stream; with one replay in flight at a time they never did
-                # (profiles/r02_graph_fault_experiments.txt).  The captured graph is the same linear
-                # chain either way, so until the owner of the bad access is known a process with two-stream history
-                # keeps one replay in flight.  (A graph Trainer itself never uses a second stream.)
+            if ops.side_stream_history() and not sihl_amd.graph_replay_safe():
+                # (rounds 1-3 mitigation, kept for processes that replay through ROCm's graph packet capture: replays queued
+                # back to back faulted after eager two-stream steps, one replay in flight at a time never did.  The cause was
+                # found in round 4 - see sihl_amd/__init__.py - and with packet capture off, the default, nothing waits here.)
                 torch.cuda.current_stream().synchronize()
         self._step_scheduler()
         return loss, metrics

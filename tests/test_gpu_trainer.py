@@ -354,3 +354,24 @@ def test_sibling_heads_report_their_validation_metrics():
     assert set(out) == {"PCK", "loss"} and 0.0 <= out["PCK"] <= 1.0
     assert kpt.pck_computer.total == 2 * 10  # every visible ground-truth keypoint is counted once per step, matched or not
 
+
+
+def test_graph_trainer_refuses_packet_capture_replays():
+    """ROCm's graph packet capture lets other device allocations overwrite a replay's kernel arguments (sihl_amd/__init__.py;
+    the graph-replay faults of rounds 1-4).  The package turns it off when it is imported before the first device call; a
+    process that touched the GPU first cannot be fixed from inside, and Trainer(graph=True) must say so instead of replaying."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "SIHL_GRAPH_ENV_EARLY")}
+    code = ("import torch; torch.zeros(8, device='cuda').add_(1); torch.cuda.synchronize(); import sihl_amd\n"
+            "from sihl_amd.train import Trainer\n"
+            "print('safe', sihl_amd.graph_replay_safe())\n"
+            "m = sihl_amd.SihlModel(sihl_amd.ResNetBackbone('resnet18'), None, [sihl_amd.heads.SemanticSegmentation([3, 64, 64, 128, 256, 512], num_classes=3)]).cuda()\n"
+            "try:\n    Trainer(m, graph=True)\n    print('constructed')\nexcept RuntimeError as e:\n    print('refused', 'packet capture' in str(e))\n")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, env=env, timeout=300)
+    assert "safe False" in p.stdout and "refused True" in p.stdout, (p.stdout[-800:], p.stderr[-800:])
+    code2 = "import sihl_amd, torch; torch.zeros(8, device='cuda'); print('safe', sihl_amd.graph_replay_safe())"
+    p = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, cwd=root, env=env, timeout=300)
+    assert "safe True" in p.stdout, (p.stdout[-800:], p.stderr[-800:])
