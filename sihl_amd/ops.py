@@ -446,15 +446,16 @@ def pyr_conv_raw(w: Tensor, x: Optional[Tensor] = None, fuse=None, bias: Optiona
     return out, stats, (x if mode == 0 else merged)
 
 
-def conv2d_wgrad_raw(x: Tensor, dout: Tensor, KH: int, KW: int, stride: int, pad: int, dil: int) -> Tensor:
-    """Returns fp32 dW [Cout][KH][KW][Cin]."""
+def conv2d_wgrad_raw(x: Tensor, dout: Tensor, KH: int, KW: int, stride: int, pad: int, dil: int, side_ok: bool = True) -> Tensor:
+    """Returns fp32 dW [Cout][KH][KW][Cin].  side_ok False: never on the side stream (the weight is not a leaf - a padded or
+    otherwise derived tensor - so autograd will run a kernel on this gradient on the main stream right away)."""
     N, H, W, Cin = x.shape
     Cout = dout.shape[-1]
     lib = _C.lib()
     # dw is a main-stream allocation either way: it is consumed on the main stream (optimizer, clipping, all-reduce) after
     # the join, and its block goes back to the main stream's pool
     dw = torch.empty((Cout, KH, KW, Cin), dtype=torch.float32, device=x.device)
-    side = _SIDE
+    side = _SIDE if side_ok else None
     if side is not None and dout.numel() // Cout <= WGRAD_SIDE_MAX_PIXELS[side.mode]:
         nbytes = _sized("sihl_conv2d_wgrad_ws_bytes", N, H, W, Cin, Cout, KH, KW, stride, pad, dil, _dt(x), SIDE_WGRAD_TARGET)
         side.stream.wait_stream(torch.cuda.current_stream())  # x and dout are complete on the main stream
@@ -755,6 +756,13 @@ class ConvBlockFn(torch.autograd.Function):
         ctx.cfg, ctx.has_norm, ctx.kshape = cfg, has_norm, (KH, KW)
         ctx.has_bias = bias is not None
         ctx.pkeys = (weight.data_ptr(),) + ((bias.data_ptr(),) if bias is not None else ())
+        # A gradient queued on the side stream may only go where no main-stream kernel touches it before the join: to a LEAF
+        # (AccumulateGrad takes it as it is).  A derived weight / bias - the zero-padded copies of odd channel counts
+        # (layers/convblocks.py: the 21-class segmentation classifier) - sends its gradient through autograd's slice / copy
+        # kernels on the main stream at once: a race with the side stream's write that round 4 found as garbage gradient norms
+        # (clip coefficient ~ 0, the SemanticSegmentation configurations stopped learning in two-stream mode).
+        ctx.side_ok_w = weight.is_leaf
+        ctx.side_ok_b = bias is None or bias.is_leaf
         if not has_norm:
             fused_ok = act in (None, "none", "relu")
             if fused_ok or not need_grad:
@@ -845,10 +853,10 @@ class ConvBlockFn(torch.autograd.Function):
         else:
             x, w, y = ctx.saved_tensors
             dz = affine_act_bwd(y, dy, None, None, "relu") if y is not None else dy
-        dbias = colsum(dz, off_chain=True) if ctx.has_bias else None
+        dbias = colsum(dz, off_chain=ctx.side_ok_b) if ctx.has_bias else None
         dw = dx = None
         if ctx.needs_input_grad[1]:
-            dw = conv2d_wgrad_raw(x, dz, KH, KW, stride, pad, dil).permute(0, 3, 1, 2)  # (O,I,KH,KW) view
+            dw = conv2d_wgrad_raw(x, dz, KH, KW, stride, pad, dil, side_ok=ctx.side_ok_w).permute(0, 3, 1, 2)  # (O,I,KH,KW) view
         if ctx.needs_input_grad[0] and ctx.dx_to is not None and ctx.dx_to.tensor is None:
             # 1x1, pad 0, stride s: dx is W^T dz at the pixels the conv reads and zero elsewhere - compute it at dz's
             # resolution (a dense stride-1 1x1 dgrad over the Ho x Wo grid) and hand it over
@@ -1333,6 +1341,7 @@ class LinearFn(torch.autograd.Function):
         rows, Cin = xd.shape
         vec = 8 if xd.dtype == torch.bfloat16 else 4
         Cout = weight.shape[0]
+        ctx.side_ok_w, ctx.side_ok_b = weight.is_leaf, bias is None or bias.is_leaf  # (see ConvBlockFn.forward)
         prep = prepared(weight, xd.dtype)
         if prep is not None:
             w, ctx.wt = prep.w.view(prep.w.shape[0], -1), prep.wt  # [Cp][Cin], [Cin][1][1][Cp]
@@ -1359,9 +1368,9 @@ class LinearFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[1]:  # first: on the side stream it then runs beside the input gradient below
-            dw = conv2d_wgrad_raw(x.view(1, 1, rows, Cin), dy.view(1, 1, rows, Cp), 1, 1, 1, 0, 1).view(Cp, Cin)[:Cout]
+            dw = conv2d_wgrad_raw(x.view(1, 1, rows, Cin), dy.view(1, 1, rows, Cp), 1, 1, 1, 0, 1, side_ok=ctx.side_ok_w).view(Cp, Cin)[:Cout]
         if ctx.has_bias and ctx.needs_input_grad[2]:  # (before dx: the side stream then does not wait for that launch)
-            db = colsum(dy, off_chain=True)[:Cout]
+            db = colsum(dy, off_chain=ctx.side_ok_b)[:Cout]
         if ctx.needs_input_grad[0]:
             wt = ctx.wt if ctx.wt is not None else weight_for_dgrad(w.view(Cp, 1, 1, Cin), flip=False)  # [Cin][1][1][Cp]
             dx, _ = conv2d_raw(dy.view(1, 1, rows, Cp), wt)

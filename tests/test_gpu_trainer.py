@@ -375,3 +375,63 @@ def test_graph_trainer_refuses_packet_capture_replays():
     code2 = "import sihl_amd, torch; torch.zeros(8, device='cuda'); print('safe', sihl_amd.graph_replay_safe())"
     p = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, cwd=root, env=env, timeout=300)
     assert "safe True" in p.stdout, (p.stdout[-800:], p.stderr[-800:])
+
+
+def test_full_size_graph_replays_survive_other_allocations():
+    """The north-star training step (ResNet50 + BiFPN + ObjectDetection, bs 32, 512^2, bf16) as ONE HIP graph, replayed five
+    times with ATen work between the replays (the L2 norm of all parameters) and 72 fresh NaN-filled allocations after the
+    fourth step: the losses must be the eager run's.  On ROCm's graph packet-capture path this exact sequence computed inf
+    (or faulted the GPU: the graph-replay fault of rounds 1-4, profiles/r04_graph_replay_root_cause.txt); the package default
+    turns that path off.  Runs tools/graph_bisect.py in a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "graph_bisect.py"), "default", "norms", "checksums"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert "[default] OK" in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])
+    losses = [float(l.split("loss ")[1].split(",")[0]) for l in p.stdout.splitlines() if "] step " in l]
+    want = [61.1518, 53.4959, 42.4053, 38.2965, 33.6236, 30.8844, 28.4207]  # the eager two-stream / single-stream trajectory
+    assert len(losses) == 7 and all(abs(a - b) < 0.5 for a, b in zip(losses, want)), losses
+    assert "changed by 72 fresh NaN-filled eager allocations: []" in p.stdout
+
+
+def test_derived_weights_keep_their_gradient_on_the_main_stream():
+    """A conv whose weight reaches the kernel through autograd ops - the zero-padded copy of an odd channel count
+    (layers/convblocks.py: 21 segmentation classes -> 24) - must NOT run its weight gradient on the side stream: autograd slices
+    that gradient on the main stream at once, before the join.  Round 4 found the race as garbage gradient norms in the
+    two-stream SemanticSegmentation configurations (profiles/r04_side_stream_leaf_race.txt).  Leaf weights still go to the side
+    stream; and a two-stream run of a 21-class segmentation model reproduces the single-stream trajectory."""
+    import sihl_amd
+    from sihl_amd import ops
+    from sihl_amd.layers.convblocks import ConvNormAct
+    from sihl_amd.train import Trainer
+    torch.manual_seed(0)
+    x = torch.randn(2, 16, 32, 32, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    for cout, expect_side in ((21, False), (24, True)):
+        blk = ConvNormAct(16, cout, kernel_size=1, norm=None, act=None).cuda().to(memory_format=torch.channels_last)
+        with ops.wgrad_side_stream("all", x.device):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = blk(x)
+            y.float().square().mean().backward()
+            used = ops.side_stream_in_use() is not None
+        assert used == expect_side, (cout, used)
+        assert torch.isfinite(blk[0].weight.grad).all() and torch.isfinite(blk[0].bias.grad).all()
+
+    def make():
+        torch.manual_seed(1)
+        bb = sihl_amd.ResNetBackbone("resnet18", top_level=5)
+        neck = sihl_amd.layers.FPN(bb.out_channels, 64, 3, 5)
+        head = sihl_amd.heads.SemanticSegmentation(neck.out_channels, num_classes=21, bottom_level=3, top_level=5, num_channels=64)
+        return sihl_amd.SihlModel(bb, neck, [head]).cuda().to(memory_format=torch.channels_last)
+
+    g = torch.Generator().manual_seed(2)
+    images = torch.rand(4, 3, 128, 128, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    target = torch.randint(0, 21, (4, 128, 128), generator=g).cuda()
+    runs = {}
+    for mode in ("all", "off", "all"):
+        tr = Trainer(make(), lr=1e-3, grad_clip_norm=0.1, autocast_dtype=torch.bfloat16, wgrad_stream=mode)
+        runs.setdefault(mode, []).append([float(tr.step(images, [target])[0]) for _ in range(6)])
+    assert runs["all"][0] == runs["all"][1], runs["all"]  # the same bits twice
+    for a, b in zip(runs["all"][0], runs["off"][0]):
+        assert abs(a - b) < 2e-2 * max(1.0, abs(b)), (runs["all"][0], runs["off"][0])
