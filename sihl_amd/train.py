@@ -419,14 +419,23 @@ class Trainer:
         static_images, static_targets = images.clone(), _tree_clone(targets)
         self.optimizer.zero_grad(set_to_none=True)  # gradients are (re)created inside the graph's memory pool
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            loss, metrics = self.forward_loss(static_images, static_targets)
-            self._backward(loss)
-            if self.grad_clip_norm is not None:
-                self._clip_gradients()
-            self.optimizer.step()
-            if self.prepared is not None:
-                self.prepared.refresh()
+        try:
+            with torch.cuda.graph(graph):
+                loss, metrics = self.forward_loss(static_images, static_targets)
+                self._backward(loss)
+                if self.grad_clip_norm is not None:
+                    self._clip_gradients()
+                self.optimizer.step()
+                if self.prepared is not None:
+                    self.prepared.refresh()
+        except RuntimeError as e:
+            if "captur" not in str(e):
+                raise
+            # (ObjectDetection and SemanticSegmentation train without a host synchronisation; the instance, keypoint,
+            # quadrilateral and depth heads keep the reference's boolean-mask indexing / nonzero, whose sizes the host must read)
+            raise RuntimeError("Trainer(graph=True): the step cannot be captured into a HIP graph - a head's training_step "
+                               "synchronises with the device (boolean-mask indexing, nonzero, .item()); use the eager "
+                               f"Trainer for this model.  [{str(e).splitlines()[0]}]") from e
         leaves = [static_images] + _tree_tensors(static_targets, [])
         return graph, leaves, loss.detach(), {k: (v.detach() if isinstance(v, Tensor) else v) for k, v in metrics.items()}
 
