@@ -57,6 +57,27 @@ def test_argument_errors_without_gpu():
     full = lib.sihl_conv2d_wgrad_ws_bytes(32, 64, 64, 256, 256, 3, 3, 1, 1, 1, 1, 0)
     half = lib.sihl_conv2d_wgrad_ws_bytes(32, 64, 64, 256, 256, 3, 3, 1, 1, 1, 1, 128)
     assert full > half > 0  # the K-split aim is a per-call argument: fewer workgroups, fewer fp32 partial slabs
+    # round 4: a 3x3 panel's tap-workgroups of one K-split share an XCD (one workgroup per CU, 32 CUs): the planner keeps
+    # every XCD's share within ONE round - 24 splits (27 workgroups per XCD), not the 28 (36 on four XCDs) a bare
+    # "256 workgroups" aim gave; 1x1 layers (one tap) still take the full aim
+    dw3 = 256 * 9 * 256 * 4
+    assert full == 24 * dw3 and half == 15 * dw3
+    assert lib.sihl_conv2d_wgrad_ws_bytes(32, 32, 32, 512, 512, 3, 3, 1, 1, 1, 1, 0) == 6 * 512 * 9 * 512 * 4  # 4 tiles x 6 splits
+    assert lib.sihl_conv2d_wgrad_ws_bytes(32, 32, 32, 256, 1024, 1, 1, 1, 0, 1, 1, 0) >= 32 * 256 * 1024 * 4
+    # sihl_grad_clip validates its tables on the host before anything is launched
+    import ctypes
+    arr = (ctypes.c_void_p * 2)(64, 128)
+    blocks = (ctypes.c_int * 1)(2)
+    assert lib.sihl_grad_clip(None, 2, 64, blocks, 64, 0.1, 64, 4, 320, None) == -1       # no pointer table
+    assert lib.sihl_grad_clip(arr, 2, 64, blocks, 64, 0.0, 64, 4, 320, None) == -1        # max_norm must be positive
+    assert lib.sihl_grad_clip(arr, 2, 64, blocks, 64, 0.1, 64, 3, 320, None) == -1        # scratch needs nblocks + 2 floats
+    assert lib.sihl_grad_clip(arr, 2, 64, blocks, 64, 0.1, 64, 4, 100, None) == -1        # group is 32 or 320
+    bad = (ctypes.c_void_p * 2)(64, 130)
+    assert lib.sihl_grad_clip(bad, 2, 64, blocks, 64, 0.1, 64, 4, 320, None) == -1        # gradients are 4-byte aligned
+    # conv_pyr.hip covers square 16-, 8-, 4-wide maps with 32-channel multiples (bf16); fused producers only 8 / 4 wide
+    assert lib.sihl_pyr_conv_supported(32, 16, 256, 256, 0) == 1 and lib.sihl_pyr_conv_supported(32, 8, 256, 256, 2) == 1
+    assert lib.sihl_pyr_conv_supported(32, 16, 256, 256, 1) == 0 and lib.sihl_pyr_conv_supported(32, 32, 256, 256, 0) == 0
+    assert lib.sihl_pyr_conv_stat_rows(32, 16) == 64 and lib.sihl_pyr_conv_stat_rows(32, 8) == 32 and lib.sihl_pyr_conv_stat_rows(30, 4) == 8
 
 
 def test_no_cpu_fallback():
