@@ -297,9 +297,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_wgrad_dma_kernel(const W
     return row * WROW + ((((cb >> 6) ^ (row & 3)) << 6) | (cb & 63));
   };
   typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  // (a thin layer fills part of the 256 x 256 panel: waves whose 64 x 64 block lies outside issue their DMA pieces and keep the
+  // barriers, nothing else)
+  const bool wave_live = co0 + wm * (MI * 32) < p.Cout && ci0 + wn * 64 < p.Cin;
   auto compute = [&](int buf, bool more, unsigned abase) {
     const char* As = smem + buf * STAGE;
     const char* Bs = As + TILE;
+    if (!wave_live) {
+      if (more) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) issue_slot(j, abase, abase + TILE);
+      }
+      return;
+    }
     // operand fragments are double-buffered in registers: the transposed reads of k-step ks+1 are in flight while
     // k-step ks multiplies (reading and multiplying back to back left the matrix pipe idle for an LDS round trip
     // per k-step)
@@ -648,7 +658,19 @@ WgradPlan plan_wgrad(long M, int N, int H, int W, int Cin, int Cout, int KH, int
     pl.splits = (int)s;
     return pl;
   }
-  const bool dma = use_dma(Cin, Cout, (long)N * H * W * Cin * vs, M * Cout * vs, dtype);
+  // thin POINTWISE layers (ResNet layer1's 64 <-> 256 and 64 -> 64 convs, the 80-class logits: hundreds of MB of activations for
+  // a few K weights) are bandwidth-bound: the panel kernel's LDS-DMA loader streams them faster than the register-staged 128 x 128
+  // kernel although a quarter or less of its 256 x 256 tile is used (waves whose channel range is empty skip their fragment
+  // reads and multiplies): 64 -> 256 95.9 -> 76.7 us (4.4 TB/s), 256 -> 64 96.9 -> 74.3, 64 -> 64 53.2 -> 42.9, 256 -> 80 on P3
+  // 35.4 -> 29.1 (tools/wgrad_thin_probe.py, profiles/r04_wgrad_thin_probe.txt)
+  // Only for launches that aim at the whole chip: beside the dgrad chain (aim 128) the register-staged kernel's 256 small
+  // workgroups fit around the main stream's kernels better than 128 panel workgroups (in-step weight-gradient time 6.08 -> 6.19 ms,
+  // profiles/r04_thin_lib_ab.txt).
+  const bool thin_pw = !g_wgrad_force_reg && dtype == SIHL_BF16 && KH * KW == 1 && (Cin < 128 || Cout < 128) &&
+                       (g_wgrad_target == 0 || g_wgrad_target >= 256) &&
+                       (Cin < Cout ? Cin : Cout) >= 64 && (Cin % 8) == 0 && (Cout % 8) == 0 &&
+                       (long)N * H * W * Cin * vs < (1L << 31) && M * Cout * vs < (1L << 31) && !getenv("SIHL_WGRAD_NO_THIN_DMA");
+  const bool dma = thin_pw || use_dma(Cin, Cout, (long)N * H * W * Cin * vs, M * Cout * vs, dtype);
   const int tb = dma ? WB : BCO;
   pl.mode = dma ? 1 : 0;
   pl.kp = dtype == SIHL_BF16 ? 64 : 32;

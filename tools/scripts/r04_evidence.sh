@@ -61,6 +61,7 @@ if [ -f tools/micro/tuning_build/libsihl_hip_wstamps.so ]; then
   SIHL_HIP_LIB=$PWD/tools/micro/tuning_build/libsihl_hip_wstamps.so timeout -k 10 120 python tools/wgrad_stamps.py > $OUT/wgrad_stamps.txt 2>&1
 fi
 timeout -k 10 200 python tools/host_phases.py > $OUT/host_phases.txt 2>&1
+(echo '== LDS-DMA panel kernel (launches that aim at the whole chip)'; timeout -k 10 200 python tools/wgrad_thin_probe.py; echo '== register-staged 128 x 128 kernel'; SIHL_WGRAD_NO_THIN_DMA=1 timeout -k 10 200 python tools/wgrad_thin_probe.py) > $OUT/wgrad_thin_probe.txt 2>&1
 # secondary configurations on the final tree
 timeout -k 10 600 python tools/config_probe.py > $OUT/config_probe.txt 2>&1
 # the bench line WITH this tree's measured traffic (profiles/r04_pmc_bench.json carries the same source stamp), CPU baseline at bs 32
