@@ -243,6 +243,12 @@ class Trainer:
             for name, p in model.named_parameters():
                 bad = p.dtype != torch.float32 or (p.dim() == 4 and p.shape[2] * p.shape[3] > 1 and
                                                    not p.is_contiguous(memory_format=torch.channels_last))
+                if getattr(p, "_backward_hooks", None):  # a tensor hook is a main-stream reader of the gradient, before the join
+                    import warnings
+                    warnings.warn(f"wgrad_stream={self.wgrad_stream!r}: {name} has a gradient hook (it would read the gradient "
+                                  "while the side stream may still be writing it): weight gradients stay on the main stream")
+                    self.wgrad_stream = "off"
+                    break
                 if bad:
                     import warnings
                     warnings.warn(f"wgrad_stream={self.wgrad_stream!r} needs fp32 parameters with channels_last conv "
